@@ -1,0 +1,213 @@
+/* C ABI of the MI355X render path: camera ray -> world intersection -> Phong
+ * shading with shadow, reflection and refraction rays, all in f64.
+ *
+ * The reference crate has no FFI layer; its boundary for this path is the Rust
+ * API `parallel_render(world, camera, jobs, out)` (src/parallel.rs:183), whose
+ * per-pixel body is `Camera::ray_for_pixel` (src/camera.rs:76) followed by
+ * `World::color_at` (src/world.rs:249) and `Canvas::write_pixel`
+ * (src/canvas.rs:114).  A host (the Rust crate through `extern "C"`, or the C++
+ * host in this repository) flattens its `World` into the plain-data
+ * description below and calls these entry points.
+ *
+ * Conventions: every function returns 0 on success or a negative rt_status;
+ * rt_last_error() gives the message of the calling thread's last failure.
+ * Nothing throws or aborts across this boundary.  Calls block until the work
+ * is done.  One caller thread per rt_scene at a time.  Pixels are row-major,
+ * index y * width + x (src/canvas.rs:120).  Matrices are row-major 4x4 like
+ * `Matrix4D` (src/matrix.rs:101-103).  Pointers named *_dev are device (HBM)
+ * addresses on the scene's GPU; all other pointers are host memory.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,     /* bad argument or inconsistent description */
+  RT_ERR_UNSUPPORTED = -2, /* valid for the reference, not built here (CSG, projective transforms) */
+  RT_ERR_DEVICE = -3,      /* HIP runtime failure */
+  RT_ERR_NOMEM = -4
+} rt_status;
+
+/* `ShapeType` leaves (src/shape.rs:23-61).  Groups become rt_gate records. */
+typedef enum rt_leaf_type {
+  RT_EMPTY = 0,
+  RT_SPHERE = 1,
+  RT_PLANE = 2,
+  RT_CUBE = 3,
+  RT_CYLINDER = 4,
+  RT_CONE = 5,
+  RT_TRIANGLE = 6,
+  RT_SMOOTH_TRIANGLE = 7
+} rt_leaf_type;
+
+/* `PatternType` (src/pattern.rs:8-32). */
+typedef enum rt_pattern_type {
+  RT_PAT_NULL = 0,
+  RT_PAT_POINT = 1,
+  RT_PAT_IDENTITY = 2,
+  RT_PAT_STRIPE = 3,
+  RT_PAT_RING = 4,
+  RT_PAT_CHECKER = 5,
+  RT_PAT_GRADIENT = 6,
+  RT_PAT_BLEND = 7
+} rt_pattern_type;
+
+/* The three cached matrices of one `Shape` (src/shape.rs:133-144). */
+typedef struct rt_xform {
+  double ray_inv[16];  /* world -> object for rays: the product of the local `transform_inverse`
+                          of every enclosing group and of the shape, applied in the order
+                          `shape::intersect` applies them (src/shape.rs:1467-1470) */
+  double full_inv[16]; /* `full_transform_inverse`, or `transform_inverse` for a top-level shape:
+                          the matrix of world_to_object / normal_to_world (src/shape.rs:757-784) */
+  double fwd[16];      /* object -> world (parent_transform * transform); used for bounds only */
+} rt_xform;
+
+/* `TriangleInfo` / `SmoothTriangleInfo` (src/geometry.rs:16-65). */
+typedef struct rt_triangle {
+  double p1[3], e1[3], e2[3], normal[3];
+  double n1[3], n2[3], n3[3]; /* smooth triangles only */
+} rt_triangle;
+
+/* One non-container `Shape`.  Leaves are listed in depth-first order of
+ * `World.objects`; that order breaks ties between equal intersection
+ * distances exactly as the reference's stable sorts do (src/intersect.rs:71-89). */
+typedef struct rt_leaf {
+  int32_t type;     /* rt_leaf_type */
+  int32_t closed;   /* cylinder / cone flag (src/shape.rs:34-37) */
+  int32_t material; /* index into materials */
+  int32_t xform;    /* index into xforms */
+  int32_t gate;     /* innermost enclosing group, index into gates, -1 at top level */
+  int32_t tri;      /* index into triangles for the two triangle types, else -1 */
+  double minimum, maximum; /* cylinder / cone extent along y */
+  double plane_normal[3];  /* `ShapeType::Plane(n)` */
+} rt_leaf;
+
+/* One `ShapeType::Group`: the bounding-box gate of `intersect_group`
+ * (src/shape.rs:1179-1222).  bmin/bmax are the group's `bounds()` exactly as
+ * the reference computes them (src/shape.rs:509-535), tested against the ray
+ * in the group's local space. */
+typedef struct rt_gate {
+  int32_t parent;      /* enclosing group or -1 */
+  int32_t reserved;
+  double to_local[16]; /* world -> group space for rays (product of local inverses) */
+  double bmin[3], bmax[3];
+} rt_gate;
+
+/* `Material` (src/light.rs:34-63). */
+typedef struct rt_material {
+  double color[3];
+  double ambient, diffuse, specular, shininess;
+  double reflective, refractive_index, transparency;
+  int32_t pattern; /* index into patterns or -1 */
+  int32_t reserved;
+} rt_material;
+
+/* `Pattern` (src/pattern.rs:34-38) with its transform already inverted
+ * (the reference inverts it on every lookup, src/pattern.rs:199). */
+typedef struct rt_pattern {
+  int32_t type;     /* rt_pattern_type */
+  int32_t first;    /* blend operands: indices into patterns */
+  int32_t second;
+  int32_t reserved;
+  double inv[16];
+  double a[3], b[3]; /* primary / secondary colour */
+} rt_pattern;
+
+/* `PointLight` (src/light.rs:11-14). */
+typedef struct rt_light {
+  double intensity[3];
+  double position[3];
+} rt_light;
+
+/* `Camera` (src/camera.rs:13-30) with `transform.inverse()` precomputed
+ * (the reference recomputes it per pixel, src/camera.rs:87). */
+typedef struct rt_camera {
+  uint32_t hsize, vsize;
+  double half_width, half_height, pixel_size;
+  double inv[16];
+} rt_camera;
+
+typedef struct rt_scene_desc {
+  rt_light light;
+  int32_t n_leaves, n_gates, n_xforms, n_triangles, n_materials, n_patterns;
+  const rt_leaf* leaves;
+  const rt_gate* gates;
+  const rt_xform* xforms;
+  const rt_triangle* triangles;
+  const rt_material* materials;
+  const rt_pattern* patterns;
+} rt_scene_desc;
+
+/* Ray counts use the reference's unit: one ray = one `World::intersect` query
+ * (primary src/world.rs:250, shadow :129, reflection :156, refraction :213). */
+typedef struct rt_stats {
+  uint64_t primary, shadow, reflect, refract;
+  double render_ms;          /* wall time of the call */
+  double trace_ms;           /* device time of the closest-hit kernels (HIP events) */
+  double shadow_ms;          /* device time of the shadow kernels */
+  uint64_t trace_launches, shadow_launches;
+  /* traversal work, filled only under RT_FLAG_COUNTERS */
+  uint64_t node_visits, tri_tests, quadric_tests, gate_tests, shaded_hits;
+} rt_stats;
+
+typedef struct rt_scene rt_scene;
+
+enum {
+  RT_FLAG_COUNTERS = 1 /* run the instrumented kernels and fill the work counters */
+};
+
+const char* rt_last_error(void);
+
+/* Number of visible GPUs, or a negative rt_status. */
+int rt_device_count(void);
+
+/* Copies the description, builds the acceleration structure over the leaves
+ * and uploads everything to `device`.  The caller keeps ownership of desc. */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Device bytes held by the scene data (acceleration structure included), and
+ * the host seconds spent building the acceleration structure. */
+int rt_scene_footprint(const rt_scene* scene, uint64_t* scene_bytes, double* build_seconds);
+
+/* `parallel_render` without the file write: renders part `part` of `n_parts`
+ * (interleaved 32x32 pixel tiles; part 0 of 1 is the whole image).  Outputs
+ * are full-size W*H images in which only this part's pixels are written; any
+ * of them may be NULL.  rgb8: the quantised bytes of `Canvas::save`
+ * (ceil(clamp(c*255)), src/canvas.rs:60-62); rgb64: the f64 colours;
+ * hit_leaf: primary hit leaf index or -1. */
+int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, uint32_t flags,
+              uint8_t* rgb8_dev, double* rgb64_dev, int32_t* hit_leaf_dev, rt_stats* stats);
+
+/* Same, into host buffers (the library stages through device memory). */
+int rt_render_host(rt_scene* scene, const rt_camera* camera, int part, int n_parts, uint32_t flags,
+                   uint8_t* rgb8, double* rgb64, int32_t* hit_leaf, rt_stats* stats);
+
+/* `Camera::ray_for_pixel` for n pixels: xy = n x (px, py); rays6 = n x
+ * (origin xyz, direction xyz).  Host buffers. */
+int rt_ray_for_pixel(rt_scene* scene, const rt_camera* camera, uint64_t n, const uint32_t* xy,
+                     double* rays6);
+
+/* `World::color_at(ray, remaining)` for n rays built with `Ray4D::new`.
+ * rgb = n x 3 doubles; leaf (nullable) = hit leaf index or -1.  Host buffers. */
+int rt_color_at(rt_scene* scene, uint64_t n, const double* rays6, int remaining, uint32_t flags,
+                double* rgb, int32_t* leaf, rt_stats* stats);
+
+/* `World::intersect` followed by `Intersections::hit`: distance (NaN when
+ * nothing is hit) and leaf index (-1).  Host buffers. */
+int rt_intersect_hit(rt_scene* scene, uint64_t n, const double* rays6, double* t, int32_t* leaf);
+
+/* `World::is_shadowed` for n points (n x 3 doubles) -> n bytes.  Host buffers. */
+int rt_is_shadowed(rt_scene* scene, uint64_t n, const double* points3, uint8_t* shadowed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,269 @@
+"""ctypes bindings of the C ABI (include/rt_amd.h) and of the host library.
+
+Names follow the reference: ``Scene`` bundles a World and a Camera as
+src/scene.rs:20-23 does, ``Scene.parallel_render`` is src/parallel.rs:183,
+``Scene.color_at`` / ``ray_for_pixel`` / ``is_shadowed`` / ``intersect_hit``
+are the batch forms of src/world.rs:249, src/camera.rs:76, src/world.rs:123 and
+src/world.rs:107 + src/intersect.rs:71.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBDIR = os.path.join(_HERE, "lib")
+
+RT_FLAG_COUNTERS = 1
+
+
+class RtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("rt status %d: %s" % (status, message))
+        self.status = status
+        self.message = message
+
+
+class RtCamera(C.Structure):
+    _fields_ = [
+        ("hsize", C.c_uint32),
+        ("vsize", C.c_uint32),
+        ("half_width", C.c_double),
+        ("half_height", C.c_double),
+        ("pixel_size", C.c_double),
+        ("inv", C.c_double * 16),
+    ]
+
+
+class RtStats(C.Structure):
+    _fields_ = [
+        ("primary", C.c_uint64),
+        ("shadow", C.c_uint64),
+        ("reflect", C.c_uint64),
+        ("refract", C.c_uint64),
+        ("render_ms", C.c_double),
+        ("trace_ms", C.c_double),
+        ("shadow_ms", C.c_double),
+        ("trace_launches", C.c_uint64),
+        ("shadow_launches", C.c_uint64),
+        ("node_visits", C.c_uint64),
+        ("tri_tests", C.c_uint64),
+        ("quadric_tests", C.c_uint64),
+        ("gate_tests", C.c_uint64),
+        ("shaded_hits", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+    @property
+    def rays(self):
+        return self.primary + self.shadow + self.reflect + self.refract
+
+
+_libs = None
+
+
+def libraries():
+    """Loads (once) and returns (librt_amd, librt_host).  Raises if they are not built."""
+    global _libs
+    if _libs is not None:
+        return _libs
+    paths = [os.path.join(_LIBDIR, n) for n in ("librt_amd.so", "librt_host.so")]
+    for p in paths:
+        if not os.path.exists(p):
+            raise RtError(-3, "%s is missing: run `make -C %s` (there is no CPU fallback)" % (p, _HERE))
+    amd = C.CDLL(paths[0], mode=C.RTLD_GLOBAL)
+    host = C.CDLL(paths[1], mode=C.RTLD_GLOBAL)
+    vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32
+    dp = C.POINTER(C.c_double)
+    amd.rt_last_error.restype = C.c_char_p
+    amd.rt_device_count.restype = i32
+    amd.rt_scene_footprint.argtypes = [vp, C.POINTER(u64), dp]
+    amd.rt_render.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
+    amd.rt_render_host.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
+    amd.rt_ray_for_pixel.argtypes = [vp, C.POINTER(RtCamera), u64, vp, vp]
+    amd.rt_color_at.argtypes = [vp, u64, vp, i32, u32, vp, vp, C.POINTER(RtStats)]
+    amd.rt_intersect_hit.argtypes = [vp, u64, vp, vp, vp]
+    amd.rt_is_shadowed.argtypes = [vp, u64, vp, vp]
+    host.rth_last_error.restype = C.c_char_p
+    host.rth_scene_from_json.argtypes = [C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]
+    host.rth_scene_free.argtypes = [vp]
+    host.rth_scene_device.argtypes = [vp]
+    host.rth_scene_device.restype = vp
+    host.rth_scene_info.argtypes = [vp, C.POINTER(u64)]
+    host.rth_scene_camera.argtypes = [vp, C.POINTER(RtCamera)]
+    host.rth_scene_set_canvas.argtypes = [vp, u64, u64]
+    host.rth_scene_set_camera.argtypes = [vp, u64, u64, C.c_double, dp, dp, dp]
+    host.rth_parallel_render.argtypes = [vp, u64, C.c_char_p]
+    host.rth_ppm_encode.argtypes = [u64, u64, vp, vp, u64]
+    host.rth_ppm_encode.restype = u64
+    _libs = (amd, host)
+    return _libs
+
+
+def device_count():
+    amd, _ = libraries()
+    n = amd.rt_device_count()
+    if n < 0:
+        raise RtError(n, amd.rt_last_error().decode())
+    return n
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def ppm_encode(rgb8):
+    """Canvas::save's text (src/canvas.rs:47-94) for an (H, W, 3) uint8 image."""
+    _, host = libraries()
+    img = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _c = img.shape
+    size = host.rth_ppm_encode(w, h, _ptr(img), None, 0)
+    buf = C.create_string_buffer(size)
+    host.rth_ppm_encode(w, h, _ptr(img), buf, size)
+    return buf.raw
+
+
+class Scene:
+    """A World and a Camera loaded from the reference's scene JSON, resident on one GPU.
+
+    device=None parses and flattens only (host logic; needs no GPU).
+    """
+
+    def __init__(self, text, base_dir="", device=0):
+        self._amd, self._host = libraries()
+        h = C.c_void_p()
+        rc = self._host.rth_scene_from_json(text.encode(), base_dir.encode(), -1 if device is None else device, C.byref(h))
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
+        self._h = h
+        self.device = device
+
+    @classmethod
+    def from_file(cls, path, base_dir=None, device=0):
+        with open(path) as f:
+            text = f.read()
+        return cls(text, os.getcwd() if base_dir is None else base_dir, device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._host.rth_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- description
+    def info(self):
+        out = (C.c_uint64 * 8)()
+        self._host.rth_scene_info(self._h, out)
+        keys = ("width", "height", "leaves", "gates", "xforms", "triangles", "materials", "patterns")
+        return dict(zip(keys, [int(v) for v in out]))
+
+    @property
+    def width(self):
+        return self.info()["width"]
+
+    @property
+    def height(self):
+        return self.info()["height"]
+
+    def camera(self):
+        cam = RtCamera()
+        rc = self._host.rth_scene_camera(self._h, C.byref(cam))
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
+        return cam
+
+    def set_canvas(self, width, height):
+        self._host.rth_scene_set_canvas(self._h, width, height)
+
+    def set_camera(self, width, height, fov, cam_from, cam_to, cam_up):
+        f = (C.c_double * 3)(*cam_from[:3])
+        t = (C.c_double * 3)(*cam_to[:3])
+        up = list(cam_up) + [0.0] * (4 - len(cam_up))
+        u = (C.c_double * 4)(*up[:4])
+        self._host.rth_scene_set_camera(self._h, width, height, fov, f, t, u)
+
+    def footprint(self):
+        b, s = C.c_uint64(), C.c_double()
+        self._check(self._amd.rt_scene_footprint(self._dev(), C.byref(b), C.byref(s)))
+        return {"scene_bytes": b.value, "build_seconds": s.value}
+
+    def _dev(self):
+        d = self._host.rth_scene_device(self._h)
+        if not d:
+            raise RtError(-3, "scene was loaded without a device")
+        return d
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(rc, self._amd.rt_last_error().decode())
+
+    # ---- rendering
+    def render(self, part=0, n_parts=1, counters=False, rgb8=True, rgb64=True, hit_leaf=True):
+        """parallel_render without the file: returns (dict of host arrays, RtStats)."""
+        cam = self.camera()
+        w, h = cam.hsize, cam.vsize
+        out = {}
+        a8 = np.zeros((h, w, 3), np.uint8) if rgb8 else None
+        a64 = np.zeros((h, w, 3), np.float64) if rgb64 else None
+        al = np.full((h, w), -1, np.int32) if hit_leaf else None
+        st = RtStats()
+        self._check(self._amd.rt_render_host(self._dev(), C.byref(cam), part, n_parts, RT_FLAG_COUNTERS if counters else 0,
+                                             _ptr(a8), _ptr(a64), _ptr(al), C.byref(st)))
+        if rgb8:
+            out["rgb8"] = a8
+        if rgb64:
+            out["rgb64"] = a64
+        if hit_leaf:
+            out["hit_leaf"] = al
+        return out, st
+
+    def render_device(self, rgb8_ptr=0, rgb64_ptr=0, hit_leaf_ptr=0, part=0, n_parts=1, counters=False):
+        """rt_render into device buffers given by address (e.g. torch tensor .data_ptr())."""
+        cam = self.camera()
+        st = RtStats()
+        self._check(self._amd.rt_render(self._dev(), C.byref(cam), part, n_parts, RT_FLAG_COUNTERS if counters else 0,
+                                        C.c_void_p(rgb8_ptr or None), C.c_void_p(rgb64_ptr or None),
+                                        C.c_void_p(hit_leaf_ptr or None), C.byref(st)))
+        return st
+
+    def parallel_render(self, jobs, out_path):
+        rc = self._host.rth_parallel_render(self._h, jobs, str(out_path).encode())
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
+
+    # ---- batch forms of the reference's per-ray API
+    def ray_for_pixel(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.uint32).reshape(-1, 2)
+        rays = np.zeros((len(xy), 6), np.float64)
+        cam = self.camera()
+        self._check(self._amd.rt_ray_for_pixel(self._dev(), C.byref(cam), len(xy), _ptr(xy), _ptr(rays)))
+        return rays
+
+    def color_at(self, rays, remaining=5, counters=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        rgb = np.zeros((len(rays), 3), np.float64)
+        leaf = np.full(len(rays), -1, np.int32)
+        st = RtStats()
+        self._check(self._amd.rt_color_at(self._dev(), len(rays), _ptr(rays), remaining,
+                                          RT_FLAG_COUNTERS if counters else 0, _ptr(rgb), _ptr(leaf), C.byref(st)))
+        return rgb, leaf, st
+
+    def intersect_hit(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        t = np.zeros(len(rays), np.float64)
+        leaf = np.full(len(rays), -1, np.int32)
+        self._check(self._amd.rt_intersect_hit(self._dev(), len(rays), _ptr(rays), _ptr(t), _ptr(leaf)))
+        return t, leaf
+
+    def is_shadowed(self, points):
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(len(pts), np.uint8)
+        self._check(self._amd.rt_is_shadowed(self._dev(), len(pts), _ptr(pts), _ptr(out)))
+        return out.astype(bool)

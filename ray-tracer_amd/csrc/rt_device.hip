@@ -1,0 +1,1758 @@
+// HIP kernels of the MI355X (gfx950) render path and the C ABI around them.
+//
+// The reference renders each pixel by recursion: Camera::ray_for_pixel
+// (src/camera.rs:76-95) -> World::color_at (src/world.rs:249-261) -> shade_hit
+// (src/world.rs:220-246) with a shadow query, a reflection ray and a refraction
+// ray per hit.  Here the recursion is unrolled into generations of rays held in
+// HBM (struct-of-arrays, one record per ray):
+//
+//   raygen -> [ trace -> shade -> shadow ] per generation -> resolve (bottom-up) -> output
+//
+// trace   closest hit of every ray against a world-space BVH (plus the
+//         refractive-index query for hits on transparent materials)
+// shade   hit point, normal, Phong terms, pattern lookup; appends the hit to the
+//         shadow queue and the reflection / refraction rays to the next
+//         generation (wave-level ballot + one atomic per wave)
+// shadow  any-hit query towards the light; picks ambient or full lighting
+// resolve walks the generations backwards and combines each ray's surface
+//         colour with its children's colours in the reference's own expression
+//         order, so the f64 result equals the recursive evaluation
+//
+// All arithmetic is f64 with the reference's operation order; build with
+// -ffp-contract=off (Rust never fuses a multiply with an add).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "bvh_build.h"
+#include "rt_types.h"
+
+using namespace rt;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+#define DEV __device__ __forceinline__
+
+struct V3 {
+  double x, y, z;
+};
+struct Ray {
+  V3 o, d;
+};
+
+DEV V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+DEV V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+// Tuple4D::dot with both w == 0 (src/tuple.rs:145-150): the w product adds +0.0
+DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV V3 cross(V3 a, V3 b) {  // src/tuple.rs:160-167
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+DEV double magnitude(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // src/tuple.rs:111-118
+DEV V3 normalize(V3 a) {  // src/tuple.rs:126-135: multiply by the reciprocal
+  double mag = magnitude(a);
+  return v3(a.x * (1.0 / mag), a.y * (1.0 / mag), a.z * (1.0 / mag));
+}
+DEV V3 reflect(V3 v, V3 n) { return v - ((n * 2.0) * dot(v, n)); }  // src/tuple.rs:170-172
+DEV bool feq(double a, double b) { return fabs(a - b) < FEQ_EPSILON; }
+
+// Matrix4D * point (w = 1) and * vector (w = 0), rows 0..2 (src/matrix.rs:638-653)
+DEV V3 mul_point(const double* m, V3 p) {
+  return v3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+            m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+DEV V3 mul_vector(const double* m, V3 v) {
+  return v3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+            m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+DEV Ray transform_ray(const double* m, const Ray& r) {  // src/ray.rs:50-55
+  return Ray{mul_point(m, r.o), mul_vector(m, r.d)};
+}
+
+struct Counters {
+  unsigned long long node_visits, tri_tests, quad_tests, gate_tests;
+};
+
+// ---------------------------------------------------------------------------
+// primitive intersection, reference src/shape.rs:839-1455
+// ---------------------------------------------------------------------------
+DEV void check_cube_axis(double origin, double direction, double& tmin, double& tmax) {  // 1367-1385
+  double tmin_numerator = -1.0 - origin;
+  double tmax_numerator = 1.0 - origin;
+  if (fabs(direction) >= FEQ_EPSILON) {
+    tmin = tmin_numerator / direction;
+    tmax = tmax_numerator / direction;
+  } else {
+    tmin = tmin_numerator * INFINITY;
+    tmax = tmax_numerator * INFINITY;
+  }
+  if (tmin > tmax) {
+    double s = tmin;
+    tmin = tmax;
+    tmax = s;
+  }
+}
+
+// Intersections of an object-space ray with one quadric-type primitive, in the
+// reference's emission order.  Returns their count (at most 4).
+DEV int intersect_quadric(int type, int closed, double minimum, double maximum, const Ray& r, double t[4]) {
+  int n = 0;
+  if (type == RT_SPHERE) {  // 839-866
+    double a = dot(r.d, r.d);
+    double b = 2.0 * dot(r.d, r.o);
+    double c = dot(r.o, r.o) - 1.0;
+    double disc = b * b - (4.0 * a * c);
+    if (disc < 0.0) return 0;
+    double sq = sqrt(disc);
+    t[0] = (-b - sq) / (2.0 * a);
+    t[1] = (-b + sq) / (2.0 * a);
+    return 2;
+  }
+  if (type == RT_PLANE) {  // 891-908
+    if (fabs(r.d.y) <= FEQ_EPSILON) return 0;
+    t[0] = -r.o.y / r.d.y;
+    return 1;
+  }
+  if (type == RT_CUBE) {  // 925-953
+    double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+    check_cube_axis(r.o.x, r.d.x, xtmin, xtmax);
+    check_cube_axis(r.o.y, r.d.y, ytmin, ytmax);
+    check_cube_axis(r.o.z, r.d.z, ztmin, ztmax);
+    double tmin = fmax(fmax(xtmin, ytmin), ztmin);  // NaN-ignoring like f64::max
+    double tmax = fmin(fmin(xtmax, ytmax), ztmax);
+    if (tmin > tmax) return 0;
+    t[0] = tmin;
+    t[1] = tmax;
+    return 2;
+  }
+  if (type == RT_CYLINDER || type == RT_CONE) {
+    const bool cone = type == RT_CONE;
+    double a, b, c;
+    if (!cone) {  // 987-1001
+      a = r.d.x * r.d.x + r.d.z * r.d.z;
+      b = 2.0 * r.o.x * r.d.x + 2.0 * r.o.z * r.d.z;
+      c = r.o.x * r.o.x + r.o.z * r.o.z - 1.0;
+    } else {  // 1077-1087
+      a = r.d.x * r.d.x - r.d.y * r.d.y + r.d.z * r.d.z;
+      b = 2.0 * r.o.x * r.d.x - 2.0 * r.o.y * r.d.y + 2.0 * r.o.z * r.d.z;
+      c = r.o.x * r.o.x - r.o.y * r.o.y + r.o.z * r.o.z;
+    }
+    // Cylinder caps exist when closed; cone caps when NOT closed (1396 vs 1431).
+    const bool caps = (cone ? !closed : (closed != 0)) && !(fabs(r.d.y) < FEQ_EPSILON);
+    bool walls = true;
+    if (!cone) {
+      if (a < FEQ_EPSILON) walls = false;  // 990-994: caps only
+    } else if (fabs(a) < FEQ_EPSILON) {    // 1089-1103: caps first, then the single root
+      walls = false;
+    }
+    if (walls) {
+      double disc = b * b - 4.0 * a * c;
+      if (disc < 0.0) return 0;  // 1004-1006 / 1108-1110: no caps either
+      double sq = sqrt(disc);
+      double t0 = (-b - sq) / (2.0 * a);
+      double t1 = (-b + sq) / (2.0 * a);
+      if (t0 > t1) {
+        double s = t0;
+        t0 = t1;
+        t1 = s;
+      }
+      double y0 = r.o.y + t0 * r.d.y;
+      if (minimum < y0 && y0 < maximum) t[n++] = t0;
+      double y1 = r.o.y + t1 * r.d.y;
+      if (minimum < y1 && y1 < maximum) t[n++] = t1;
+    }
+    if (caps) {  // 1388-1455
+      double tl = (minimum - r.o.y) / r.d.y;
+      double xl = r.o.x + tl * r.d.x, zl = r.o.z + tl * r.d.z;
+      double tu = (maximum - r.o.y) / r.d.y;
+      double xu = r.o.x + tu * r.d.x, zu = r.o.z + tu * r.d.z;
+      double rl = cone ? minimum * minimum : 1.0;
+      double ru = cone ? maximum * maximum : 1.0;
+      if (xl * xl + zl * zl <= rl) t[n++] = tl;
+      if (xu * xu + zu * zu <= ru) t[n++] = tu;
+    }
+    if (cone && !walls && !(fabs(b) < FEQ_EPSILON)) t[n++] = -c / (2.0 * b);  // 1097-1102
+    return n;
+  }
+  return 0;  // RT_EMPTY
+}
+
+// Moller-Trumbore as the reference writes it (src/shape.rs:1225-1260, 1273-1315).
+DEV bool intersect_triangle(const TriIsect& tr, const Ray& r, double& t, double& u, double& v) {
+  V3 e1 = v3(tr.e1[0], tr.e1[1], tr.e1[2]), e2 = v3(tr.e2[0], tr.e2[1], tr.e2[2]);
+  V3 dir_cross_e2 = cross(r.d, e2);
+  double det = dot(e1, dir_cross_e2);
+  if (fabs(det) < FEQ_EPSILON) return false;
+  double f = 1.0 / det;
+  V3 p1_to_origin = r.o - v3(tr.p1[0], tr.p1[1], tr.p1[2]);
+  u = f * dot(p1_to_origin, dir_cross_e2);
+  if (u < 0.0) return false;
+  V3 origin_cross_e1 = cross(p1_to_origin, e1);
+  v = f * dot(r.d, origin_cross_e1);
+  if (v < 0.0 || u + v > 1.0) return false;
+  t = f * dot(e2, origin_cross_e1);
+  return true;
+}
+
+// The bounding-box gate of intersect_group (src/shape.rs:1191-1211) with
+// Bounds::check_axis (src/geometry.rs:160-179), in the group's own space.
+DEV void gate_axis(double mn, double mx, double origin, double direction, double& tmin, double& tmax) {
+  double tmin_numerator = mn - origin;
+  double tmax_numerator = mx - origin;
+  if (fabs(direction) >= FEQ_EPSILON) {
+    tmin = tmin_numerator / direction;
+    tmax = tmax_numerator / direction;
+  } else {
+    tmin = tmin_numerator * INFINITY;
+    tmax = tmax_numerator * INFINITY;
+  }
+  if (tmin > tmax) {
+    double s = tmin;
+    tmin = tmax;
+    tmax = s;
+  }
+}
+DEV bool gate_passes(const Gate& g, const Ray& world_ray) {
+  Ray r = transform_ray(g.m, world_ray);
+  double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+  gate_axis(g.bmin[0], g.bmax[0], r.o.x, r.d.x, xtmin, xtmax);
+  gate_axis(g.bmin[1], g.bmax[1], r.o.y, r.d.y, ytmin, ytmax);
+  gate_axis(g.bmin[2], g.bmax[2], r.o.z, r.d.z, ztmin, ztmax);
+  double tmin = fmax(fmax(xtmin, ytmin), ztmin);
+  double tmax = fmin(fmin(xtmax, ytmax), ztmax);
+  return !(tmin > tmax);
+}
+
+// ---------------------------------------------------------------------------
+// query policies
+// ---------------------------------------------------------------------------
+// Closest hit = first finite t >= 0 of the stably sorted list
+// (src/intersect.rs:71-89); equal t resolves to the lower depth-first leaf.
+struct ClosestQuery {
+  double best_t;
+  int best_leaf;
+  double u, v;
+  DEV void init() {
+    best_t = INFINITY;
+    best_leaf = 0x7FFFFFFF;
+    u = v = 0.0;
+  }
+  DEV double lo() const { return 0.0; }
+  DEV double hi() const { return best_t; }
+  DEV bool done() const { return false; }
+  DEV void offer(double t, int leaf, double uu, double vv) {
+    if (t >= 0.0 && isfinite(t) && (t < best_t || (t == best_t && leaf < best_leaf))) {
+      best_t = t;
+      best_leaf = leaf;
+      u = uu;
+      v = vv;
+    }
+  }
+  DEV void leaf_ts(int leaf, int n, const double* t) {
+    for (int i = 0; i < n; i++) offer(t[i], leaf, 0.0, 0.0);
+  }
+  DEV void leaf_tri(int leaf, double t, double uu, double vv) { offer(t, leaf, uu, vv); }
+};
+
+// World::is_shadowed (src/world.rs:123-137): some finite 0 <= t < distance exists.
+struct ShadowQuery {
+  double distance;
+  bool found;
+  DEV double lo() const { return 0.0; }
+  DEV double hi() const { return distance; }
+  DEV bool done() const { return found; }
+  DEV void leaf_ts(int, int n, const double* t) {
+    for (int i = 0; i < n; i++)
+      if (t[i] >= 0.0 && t[i] < distance) found = true;  // a finite bound keeps out +inf; NaN fails both
+  }
+  DEV void leaf_tri(int, double t, double, double) {
+    if (t >= 0.0 && t < distance) found = true;
+  }
+};
+
+// refraction_indices (src/intersect.rs:191-234) as a streaming query: the list
+// walk up to the hit only sees intersections with t < 0.  A shape is still in
+// `containers` there iff it has an odd number of them, and its position in the
+// vector is decided by its largest negative t (ties: depth-first order).
+struct ContainerQuery {
+  int hit_leaf;
+  bool hit_inside;
+  double hit_key;
+  double other_key;
+  int other_leaf;
+  DEV void init(int leaf) {
+    hit_leaf = leaf;
+    hit_inside = false;
+    hit_key = -INFINITY;
+    other_key = -INFINITY;
+    other_leaf = -1;
+  }
+  DEV double lo() const { return -INFINITY; }
+  DEV double hi() const { return 0.0; }
+  DEV bool done() const { return false; }
+  DEV void container(int leaf, int count, double key) {
+    if (!(count & 1)) return;
+    if (leaf == hit_leaf) {
+      hit_inside = true;
+      hit_key = key;
+    } else if (key > other_key || (key == other_key && leaf > other_leaf)) {
+      other_key = key;
+      other_leaf = leaf;
+    }
+  }
+  DEV void leaf_ts(int leaf, int n, const double* t) {
+    int count = 0;
+    double key = -INFINITY;
+    for (int i = 0; i < n; i++)
+      if (t[i] < 0.0 && isfinite(t[i])) {
+        count++;
+        key = fmax(key, t[i]);
+      }
+    container(leaf, count, key);
+  }
+  DEV void leaf_tri(int leaf, double t, double, double) {
+    if (t < 0.0 && isfinite(t)) container(leaf, 1, t);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// traversal
+// ---------------------------------------------------------------------------
+// Per-lane stack in LDS: entry e of thread t lives at stack[e * BLOCK + t], so
+// the 64 lanes of a wave hit 64 consecutive banks.
+template <int STACK, int BLOCK>
+struct LdsStack {
+  uint32_t* base;
+  int sp;
+  DEV void init(uint32_t* lds) {
+    base = lds + threadIdx.x;
+    sp = 0;
+  }
+  DEV void push(uint32_t r) {
+    if (sp < STACK) base[(sp++) * BLOCK] = r;
+  }
+  DEV uint32_t pop() { return base[(--sp) * BLOCK]; }
+  DEV bool empty() const { return sp == 0; }
+  DEV void clear() { sp = 0; }
+};
+
+DEV void slab(const double* lo, const double* hi, const V3& o, const V3& inv, double& tn, double& tf) {
+  double tx0 = (lo[0] - o.x) * inv.x, tx1 = (hi[0] - o.x) * inv.x;
+  double ty0 = (lo[1] - o.y) * inv.y, ty1 = (hi[1] - o.y) * inv.y;
+  double tz0 = (lo[2] - o.z) * inv.z, tz1 = (hi[2] - o.z) * inv.z;
+  // fmin/fmax drop a NaN operand (0 * inf when the origin lies on a slab plane of a parallel ray)
+  tn = fmax(fmax(fmin(tx0, tx1), fmin(ty0, ty1)), fmin(tz0, tz1));
+  tf = fmin(fmin(fmax(tx0, tx1), fmax(ty0, ty1)), fmax(tz0, tz1));
+}
+
+template <class Query>
+DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& Q, bool check_gates) {
+  if (check_gates) {
+    for (int g = q.gate; g >= 0; g = S.gates[g].parent)
+      if (!gate_passes(S.gates[g], ray)) return;
+  }
+  Ray local = transform_ray(q.m, ray);  // src/shape.rs:1468
+  double t[4];
+  int n = intersect_quadric(q.type, q.closed, q.minimum, q.maximum, local, t);
+  if (n) Q.leaf_ts(q.leaf, n, t);
+}
+
+template <class Query, class Stack, bool COUNT>
+DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counters& cnt) {
+  for (int i = 0; i < S.n_unbounded; i++) {
+    if (COUNT) cnt.quad_tests++;
+    test_quad(S, S.unbounded[i], ray, Q, true);
+  }
+  if (S.root == REF_NONE || Q.done()) return;
+  const V3 inv = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+  st.clear();
+  st.push(S.root);
+  while (!st.empty()) {
+    uint32_t ref = st.pop();
+    uint32_t kind = ref >> 30;
+    if (kind == KIND_INNER) {
+      const BvhNode& nd = S.nodes[ref & 0x3FFFFFFFu];
+      if (COUNT) cnt.node_visits++;
+      double tn0, tf0, tn1, tf1;
+      slab(nd.lo0, nd.hi0, ray.o, inv, tn0, tf0);
+      slab(nd.lo1, nd.hi1, ray.o, inv, tn1, tf1);
+      const double lo = Q.lo(), hi = Q.hi();
+      bool h0 = fmax(tn0, lo) <= fmin(tf0, hi);
+      bool h1 = fmax(tn1, lo) <= fmin(tf1, hi);
+      uint32_t c0 = nd.c0, c1 = nd.c1;
+      if (h0 && h1) {
+        if (tn1 < tn0) {  // nearer child on top
+          st.push(c0);
+          st.push(c1);
+        } else {
+          st.push(c1);
+          st.push(c0);
+        }
+      } else if (h0) {
+        st.push(c0);
+      } else if (h1) {
+        st.push(c1);
+      }
+    } else if (kind == KIND_TRI) {
+      uint32_t first = ref & MAX_RUN_FIRST, count = ((ref >> 27) & 7u) + 1u;
+      for (uint32_t i = 0; i < count; i++) {
+        const TriIsect& tr = S.tris[first + i];
+        if (COUNT) cnt.tri_tests++;
+        double t, u, v;
+        bool hit;
+        if (tr.xform >= 0) {
+          Ray local = transform_ray(S.xforms[tr.xform].ray_inv, ray);
+          hit = intersect_triangle(tr, local, t, u, v);
+        } else {
+          hit = intersect_triangle(tr, ray, t, u, v);
+        }
+        if (hit) Q.leaf_tri(tr.leaf, t, u, v);
+      }
+      if (Q.done()) return;
+    } else if (kind == KIND_QUAD) {
+      uint32_t first = ref & MAX_RUN_FIRST, count = ((ref >> 27) & 7u) + 1u;
+      for (uint32_t i = 0; i < count; i++) {
+        if (COUNT) cnt.quad_tests++;
+        test_quad(S, S.quads[first + i], ray, Q, false);
+      }
+      if (Q.done()) return;
+    } else {
+      const Gate& g = S.gates[ref & 0x3FFFFFFFu];
+      if (COUNT) cnt.gate_tests++;
+      if (g.root != REF_NONE && gate_passes(g, ray)) st.push(g.root);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ray records: one generation = struct of arrays in HBM
+// ---------------------------------------------------------------------------
+struct GenView {
+  double *ox, *oy, *oz, *dx, *dy, *dz;          // ray
+  double *t, *u, *v, *n1, *n2;                  // hit
+  int32_t* leaf;                                // hit leaf or -1
+  double *px, *py, *pz;                         // over_point (shadow ray origin)
+  double *ar, *ag, *ab;                         // ambient term
+  double *lr, *lg, *lb;                         // ambient + diffuse + specular
+  double *cr, *cg, *cb;                         // surface colour, then the ray's final colour
+  double *reflective, *transparency, *reflectance;  // mix factors of this hit
+  uint32_t *child_reflect, *child_refract;      // indices into the next generation or REF_NONE
+  uint32_t* flags;                              // bit0: hit, bit1: Schlick mix
+  uint32_t* shadow_queue;                       // compacted indices of rays that hit something
+};
+
+DEV Ray load_ray(const GenView& g, uint32_t i) {
+  return Ray{v3(g.ox[i], g.oy[i], g.oz[i]), v3(g.dx[i], g.dy[i], g.dz[i])};
+}
+
+struct CameraDev {
+  uint32_t hsize, vsize;
+  double half_width, half_height, pixel_size;
+  double inv[12];
+};
+
+constexpr int TILE = 32;         // multi-GPU partition granule, pixels per side
+constexpr int TILE_PIXELS = TILE * TILE;
+constexpr int BLOCK = 256;
+
+// Ray index -> pixel: tile k of this part, then 8x8 pixel blocks per wave so the
+// 64 rays of a wave stay close in screen space.
+DEV bool ray_pixel(const uint32_t* tiles, uint32_t tiles_x, const CameraDev& cam, uint32_t i, uint32_t& x,
+                   uint32_t& y) {
+  uint32_t tile = tiles[i / TILE_PIXELS];
+  uint32_t in_tile = i % TILE_PIXELS;
+  uint32_t wave = in_tile >> 6, lane = in_tile & 63u;
+  x = (tile % tiles_x) * TILE + (wave & 3u) * 8u + (lane & 7u);
+  y = (tile / tiles_x) * TILE + (wave >> 2) * 8u + (lane >> 3);
+  return x < cam.hsize && y < cam.vsize;
+}
+
+// Camera::ray_for_pixel (src/camera.rs:76-95) with the inverse precomputed.
+DEV Ray camera_ray(const CameraDev& cam, uint32_t px, uint32_t py) {
+  double xoffset = ((double)px + 0.5) * cam.pixel_size;
+  double yoffset = ((double)py + 0.5) * cam.pixel_size;
+  double world_x = cam.half_width - xoffset;
+  double world_y = cam.half_height - yoffset;
+  V3 pixel = mul_point(cam.inv, v3(world_x, world_y, -1.0));
+  V3 origin = mul_point(cam.inv, v3(0.0, 0.0, 0.0));
+  V3 direction = normalize(pixel - origin);
+  return Ray{origin, direction};
+}
+
+__global__ void __launch_bounds__(BLOCK) k_raygen(GenView g, uint32_t n, CameraDev cam, const uint32_t* tiles,
+                                                  uint32_t tiles_x) {
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x, y;
+  if (!ray_pixel(tiles, tiles_x, cam, i, x, y)) {
+    g.leaf[i] = -2;  // outside the image: never traced
+    return;
+  }
+  Ray r = camera_ray(cam, x, y);
+  g.ox[i] = r.o.x; g.oy[i] = r.o.y; g.oz[i] = r.o.z;
+  g.dx[i] = r.d.x; g.dy[i] = r.d.y; g.dz[i] = r.d.z;
+  g.leaf[i] = -1;
+}
+
+// Rays supplied by the caller (rt_color_at and friends): Ray4D::new keeps the
+// three components as given.
+__global__ void __launch_bounds__(BLOCK) k_load_rays(GenView g, uint32_t n, const double* rays6) {
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double* r = rays6 + (size_t)i * 6;
+  g.ox[i] = r[0]; g.oy[i] = r[1]; g.oz[i] = r[2];
+  g.dx[i] = r[3]; g.dy[i] = r[4]; g.dz[i] = r[5];
+  g.leaf[i] = -1;
+}
+
+DEV void flush_counters(const Counters& c, unsigned long long* out) {
+  // one atomic per wave and counter
+  unsigned long long v[4] = {c.node_visits, c.tri_tests, c.quad_tests, c.gate_tests};
+  for (int k = 0; k < 4; k++) {
+    unsigned long long s = v[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&out[k], s);
+  }
+}
+
+template <int STACK, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_trace(SceneDev S, GenView g, uint32_t n, unsigned long long* counters) {
+  __shared__ uint32_t lds[STACK * BLOCK];
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  Counters cnt = {0, 0, 0, 0};
+  if (i < n && g.leaf[i] != -2) {
+    LdsStack<STACK, BLOCK> st;
+    st.init(lds);
+    Ray ray = load_ray(g, i);
+    ClosestQuery Q;
+    Q.init();
+    traverse<ClosestQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, Q, st, cnt);
+    if (Q.best_leaf == 0x7FFFFFFF) {
+      g.leaf[i] = -1;
+    } else {
+      g.leaf[i] = Q.best_leaf;
+      g.t[i] = Q.best_t;
+      g.u[i] = Q.u;
+      g.v[i] = Q.v;
+      const MaterialDev& m = S.materials[S.leaves[Q.best_leaf].material];
+      if (m.flags & 8) {  // n1 / n2 are consumed: refraction or Schlick
+        ContainerQuery C;
+        C.init(Q.best_leaf);
+        traverse<ContainerQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, C, st, cnt);
+        double ri_hit = m.refractive_index;
+        double ri_other = C.other_leaf >= 0 ? S.materials[S.leaves[C.other_leaf].material].refractive_index : 1.0;
+        double n1, n2;
+        if (C.hit_inside) {
+          bool hit_last = C.other_leaf < 0 || C.hit_key > C.other_key ||
+                          (C.hit_key == C.other_key && C.hit_leaf > C.other_leaf);
+          n1 = hit_last ? ri_hit : ri_other;
+          n2 = ri_other;
+        } else {
+          n1 = ri_other;
+          n2 = ri_hit;
+        }
+        g.n1[i] = n1;
+        g.n2[i] = n2;
+      }
+    }
+  }
+  if (COUNT) flush_counters(cnt, counters);
+}
+
+// ---------------------------------------------------------------------------
+// shading
+// ---------------------------------------------------------------------------
+DEV double rem_euclid2(double x) {  // f64::rem_euclid(2.0)
+  double r = fmod(x, 2.0);
+  return r < 0.0 ? r + 2.0 : r;
+}
+
+// Pattern::pattern_at (src/pattern.rs:97-189).  Blend operands are evaluated at
+// the same point with no transform of their own (src/pattern.rs:185-186).
+template <int DEPTH>
+DEV void pattern_at(const SceneDev& S, int idx, V3 p, double& r, double& g, double& b) {
+  const PatternDev& pt = S.patterns[idx];
+  bool primary = true;
+  switch (pt.type) {
+    case RT_PAT_NULL: r = g = b = 0.0; return;
+    case RT_PAT_POINT: r = p.x; g = p.y; b = p.z; return;
+    case RT_PAT_IDENTITY: r = pt.a[0]; g = pt.a[1]; b = pt.a[2]; return;
+    case RT_PAT_STRIPE: primary = feq(rem_euclid2(floor(p.x)), 0.0); break;
+    case RT_PAT_RING: primary = feq(rem_euclid2(floor(sqrt(p.x * p.x + p.z * p.z))), 0.0); break;
+    case RT_PAT_CHECKER: primary = feq(rem_euclid2(floor(p.x) + floor(p.y) + floor(p.z)), 0.0); break;
+    case RT_PAT_GRADIENT: {
+      double fraction = p.x - floor(p.x);
+      r = pt.a[0] + (pt.b[0] - pt.a[0]) * fraction;
+      g = pt.a[1] + (pt.b[1] - pt.a[1]) * fraction;
+      b = pt.a[2] + (pt.b[2] - pt.a[2]) * fraction;
+      return;
+    }
+    case RT_PAT_BLEND: {
+      if constexpr (DEPTH > 0) {
+        double r1, g1, b1, r2, g2, b2;
+        pattern_at<DEPTH - 1>(S, pt.first, p, r1, g1, b1);
+        pattern_at<DEPTH - 1>(S, pt.second, p, r2, g2, b2);
+        r = (r1 + r2) / 2.0; g = (g1 + g2) / 2.0; b = (b1 + b2) / 2.0;  // src/color.rs:169-175
+      } else {
+        r = g = b = 0.0;
+      }
+      return;
+    }
+    default: r = g = b = 0.0; return;
+  }
+  r = primary ? pt.a[0] : pt.b[0];
+  g = primary ? pt.a[1] : pt.b[1];
+  b = primary ? pt.a[2] : pt.b[2];
+}
+constexpr int MAX_BLEND_DEPTH = 4;
+
+// local_normal_at (src/shape.rs:805-829, per-type routines 880-1173, 1263-1332)
+DEV V3 local_normal(const SceneDev& S, const LeafShade& L, V3 at, double u, double v) {
+  switch (L.type) {
+    case RT_PLANE: return v3(L.plane_normal[0], L.plane_normal[1], L.plane_normal[2]);
+    case RT_CUBE: {
+      double xa = fabs(at.x), ya = fabs(at.y), za = fabs(at.z);
+      double max_component = fmax(fmax(xa, ya), za);
+      if (max_component == xa) return v3(at.x, 0.0, 0.0);
+      if (max_component == ya) return v3(0.0, at.y, 0.0);
+      return v3(0.0, 0.0, at.z);
+    }
+    case RT_CYLINDER:
+    case RT_CONE: {
+      double dist = at.x * at.x + at.z * at.z;
+      if (dist < 1.0 && at.y >= L.maximum - FEQ_EPSILON) return v3(0.0, 1.0, 0.0);
+      if (dist < 1.0 && at.y <= L.minimum + FEQ_EPSILON) return v3(0.0, -1.0, 0.0);
+      if (L.type == RT_CYLINDER) return v3(at.x, 0.0, at.z);
+      double y = sqrt(dist);
+      if (at.y > 0.0) y = -y;
+      return v3(at.x, y, at.z);
+    }
+    case RT_TRIANGLE: {
+      const TriShade& ts = S.tri_shade[L.tri];
+      return v3(ts.normal[0], ts.normal[1], ts.normal[2]);
+    }
+    case RT_SMOOTH_TRIANGLE: {
+      const TriShade& ts = S.tri_shade[L.tri];
+      double w = 1.0 - u - v;  // n2 * u + n3 * v + n1 * (1 - u - v)
+      return v3(ts.n2[0] * u + ts.n3[0] * v + ts.n1[0] * w, ts.n2[1] * u + ts.n3[1] * v + ts.n1[1] * w,
+                ts.n2[2] * u + ts.n3[2] * v + ts.n1[2] * w);
+    }
+    default: return at;  // sphere, empty: the point with w = 0
+  }
+}
+
+// Appends `mine` items per lane to a queue: one atomic per wave, prefix by ballot.
+DEV uint32_t wave_append(uint32_t* counter, bool mine) {
+  unsigned long long mask = __ballot(mine);
+  uint32_t lane = threadIdx.x & 63u;
+  uint32_t total = (uint32_t)__popcll(mask);
+  uint32_t base = 0;
+  if (lane == 0 && total) base = atomicAdd(counter, total);
+  base = __shfl(base, 0);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// IntersectionComputation::new (src/intersect.rs:152-184), lighting
+// (src/light.rs:125-174) up to the shadow flag, reflected_color / refracted_color
+// ray set-up (src/world.rs:142-215) and Schlick (src/intersect.rs:240-260).
+__global__ void __launch_bounds__(BLOCK)
+    k_shade(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_capacity, int remaining,
+            uint32_t* shadow_count, uint32_t* next_count, unsigned long long* stats) {
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  bool active = i < n;
+  int leaf = active ? g.leaf[i] : -1;
+  bool hit = leaf >= 0;
+  bool want_reflect = false, want_refract = false;
+  Ray reflect_ray, refract_ray;
+  if (active) {
+    g.child_reflect[i] = REF_NONE;
+    g.child_refract[i] = REF_NONE;
+    g.flags[i] = hit ? 1u : 0u;
+    if (!hit) {  // World::color_at: None => black
+      g.cr[i] = 0.0; g.cg[i] = 0.0; g.cb[i] = 0.0;
+    }
+  }
+  if (hit) {
+    const LeafShade L = S.leaves[leaf];
+    const MaterialDev m = S.materials[L.material];
+    const XformDev& X = S.xforms[L.xform];
+    Ray ray = load_ray(g, i);
+    double t = g.t[i];
+    V3 point = ray.o + (ray.d * t);  // Ray4D::position
+    V3 eyev = -ray.d;
+    // normal_at (src/shape.rs:1478-1484)
+    V3 local_point = mul_point(X.full_inv, point);
+    V3 ln = local_normal(S, L, local_point, g.u[i], g.v[i]);
+    const double* fi = X.full_inv;  // transposition() * normal, w dropped, normalize
+    V3 normalv = normalize(v3(fi[0] * ln.x + fi[4] * ln.y + fi[8] * ln.z, fi[1] * ln.x + fi[5] * ln.y + fi[9] * ln.z,
+                              fi[2] * ln.x + fi[6] * ln.y + fi[10] * ln.z));
+    if (dot(normalv, eyev) < 0.0) normalv = -normalv;
+    V3 over_point = point + normalv * FEQ_EPSILON;
+    V3 under_point = point - normalv * FEQ_EPSILON;
+    V3 reflectv = reflect(ray.d, normalv);
+
+    // lighting(): evaluated at over_point, pattern included (src/world.rs:223-227)
+    double cr, cg, cb;
+    if (m.pattern >= 0) {
+      V3 object_point = mul_point(X.full_inv, over_point);
+      V3 pattern_point = mul_point(S.patterns[m.pattern].inv, object_point);
+      pattern_at<MAX_BLEND_DEPTH>(S, m.pattern, pattern_point, cr, cg, cb);
+    } else {
+      cr = m.color[0]; cg = m.color[1]; cb = m.color[2];
+    }
+    double er = cr * S.light_intensity[0], eg = cg * S.light_intensity[1], eb = cb * S.light_intensity[2];
+    V3 lightpos = v3(S.light_position[0], S.light_position[1], S.light_position[2]);
+    V3 lightv = normalize(lightpos - over_point);
+    double ar = er * m.ambient, ag = eg * m.ambient, ab = eb * m.ambient;
+    double dr = 0.0, dg = 0.0, db = 0.0, sr = 0.0, sg = 0.0, sb = 0.0;
+    double light_dot_normal = dot(lightv, normalv);
+    if (!(light_dot_normal < 0.0)) {
+      dr = er * m.diffuse * light_dot_normal;
+      dg = eg * m.diffuse * light_dot_normal;
+      db = eb * m.diffuse * light_dot_normal;
+      V3 rv = reflect(-lightv, normalv);
+      double reflect_dot_eye = dot(rv, eyev);
+      if (!(reflect_dot_eye <= 0.0)) {
+        double factor = pow(reflect_dot_eye, m.shininess);
+        sr = S.light_intensity[0] * m.specular * factor;
+        sg = S.light_intensity[1] * m.specular * factor;
+        sb = S.light_intensity[2] * m.specular * factor;
+      }
+    }
+    g.px[i] = over_point.x; g.py[i] = over_point.y; g.pz[i] = over_point.z;
+    g.ar[i] = ar; g.ag[i] = ag; g.ab[i] = ab;
+    g.lr[i] = ar + dr + sr; g.lg[i] = ag + dg + sg; g.lb[i] = ab + db + sb;
+    g.reflective[i] = m.reflective;
+    g.transparency[i] = m.transparency;
+
+    // reflected_color (src/world.rs:142-159)
+    if (remaining != 0 && (m.flags & 1)) {
+      want_reflect = true;
+      reflect_ray = Ray{over_point, reflectv};
+    }
+    double n1 = 1.0, n2 = 1.0;
+    if (m.flags & 8) {
+      n1 = g.n1[i];
+      n2 = g.n2[i];
+    }
+    // refracted_color (src/world.rs:181-215)
+    if (remaining != 0 && (m.flags & 2)) {
+      double n_ratio = n1 / n2;
+      double cos_i = dot(eyev, normalv);
+      double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+      if (!(sin2_t > 1.0)) {
+        double cos_t = sqrt(1.0 - sin2_t);
+        V3 direction = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
+        want_refract = true;
+        refract_ray = Ray{under_point, direction};
+      }
+    }
+    if (m.flags & 4) {  // schlick (src/intersect.rs:240-260)
+      double cosv = dot(eyev, normalv);
+      double reflectance;
+      bool total = false;
+      if (n1 > n2) {
+        double nn = n1 / n2;
+        double sin2_t = (nn * nn) * (1.0 - cosv * cosv);
+        if (sin2_t > 1.0) total = true;
+        else cosv = sqrt(1.0 - sin2_t);
+      }
+      if (total) {
+        reflectance = 1.0;
+      } else {
+        double q = (n1 - n2) / (n1 + n2);
+        double r0 = q * q;
+        double x = 1.0 - cosv;
+        double x2 = x * x;
+        reflectance = r0 + (1.0 - r0) * (x * (x2 * x2));  // powi(5)
+      }
+      g.reflectance[i] = reflectance;
+      g.flags[i] = 3u;
+    }
+  }
+  // queues: shadow rays of this generation, rays of the next generation
+  uint32_t sq = wave_append(shadow_count, hit);
+  if (hit) g.shadow_queue[sq] = i;
+  uint32_t ri = wave_append(next_count, want_reflect);
+  if (want_reflect && ri < next_capacity) {
+    next.ox[ri] = reflect_ray.o.x; next.oy[ri] = reflect_ray.o.y; next.oz[ri] = reflect_ray.o.z;
+    next.dx[ri] = reflect_ray.d.x; next.dy[ri] = reflect_ray.d.y; next.dz[ri] = reflect_ray.d.z;
+    next.leaf[ri] = -1;
+    g.child_reflect[i] = ri;
+  }
+  uint32_t ti = wave_append(next_count, want_refract);
+  if (want_refract && ti < next_capacity) {
+    next.ox[ti] = refract_ray.o.x; next.oy[ti] = refract_ray.o.y; next.oz[ti] = refract_ray.o.z;
+    next.dx[ti] = refract_ray.d.x; next.dy[ti] = refract_ray.d.y; next.dz[ti] = refract_ray.d.z;
+    next.leaf[ti] = -1;
+    g.child_refract[i] = ti;
+  }
+  // ray statistics: [4] shaded hits, [5] reflection rays, [6] refraction rays
+  unsigned long long hm = __ballot(hit), rm = __ballot(want_reflect), fm = __ballot(want_refract);
+  if ((threadIdx.x & 63) == 0) {
+    if (hm) atomicAdd(&stats[4], (unsigned long long)__popcll(hm));
+    if (rm) atomicAdd(&stats[5], (unsigned long long)__popcll(rm));
+    if (fm) atomicAdd(&stats[6], (unsigned long long)__popcll(fm));
+  }
+}
+
+// World::is_shadowed (src/world.rs:123-137) for every queued hit, then the
+// in_shadow branch of lighting (src/light.rs:144-146).
+template <int STACK, bool COUNT>
+__global__ void __launch_bounds__(BLOCK)
+    k_shadow(SceneDev S, GenView g, const uint32_t* shadow_count, unsigned long long* counters) {
+  __shared__ uint32_t lds[STACK * BLOCK];
+  uint32_t q = blockIdx.x * BLOCK + threadIdx.x;
+  Counters cnt = {0, 0, 0, 0};
+  if (q < *shadow_count) {
+    uint32_t i = g.shadow_queue[q];
+    LdsStack<STACK, BLOCK> st;
+    st.init(lds);
+    V3 p = v3(g.px[i], g.py[i], g.pz[i]);
+    V3 lightpos = v3(S.light_position[0], S.light_position[1], S.light_position[2]);
+    V3 v = lightpos - p;
+    ShadowQuery Q;
+    Q.distance = magnitude(v);
+    Q.found = false;
+    Ray ray{p, normalize(v)};
+    traverse<ShadowQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, Q, st, cnt);
+    if (Q.found) {
+      g.cr[i] = g.ar[i]; g.cg[i] = g.ag[i]; g.cb[i] = g.ab[i];
+    } else {
+      g.cr[i] = g.lr[i]; g.cg[i] = g.lg[i]; g.cb[i] = g.lb[i];
+    }
+  }
+  if (COUNT) flush_counters(cnt, counters);
+}
+
+// shade_hit's final expression (src/world.rs:236-245), children first.
+__global__ void __launch_bounds__(BLOCK) k_resolve(GenView g, uint32_t n, GenView next) {
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t flags = g.flags[i];
+  if (!(flags & 1u)) return;
+  uint32_t cr = g.child_reflect[i], cf = g.child_refract[i];
+  double rr = 0.0, rg = 0.0, rb = 0.0, fr = 0.0, fg = 0.0, fb = 0.0;
+  if (cr != REF_NONE) {
+    double k = g.reflective[i];
+    rr = next.cr[cr] * k; rg = next.cg[cr] * k; rb = next.cb[cr] * k;
+  }
+  if (cf != REF_NONE) {
+    double k = g.transparency[i];
+    fr = next.cr[cf] * k; fg = next.cg[cf] * k; fb = next.cb[cf] * k;
+  }
+  double sr = g.cr[i], sg = g.cg[i], sb = g.cb[i];
+  if (flags & 2u) {
+    double R = g.reflectance[i];
+    g.cr[i] = sr + rr * R + fr * (1.0 - R);
+    g.cg[i] = sg + rg * R + fg * (1.0 - R);
+    g.cb[i] = sb + rb * R + fb * (1.0 - R);
+  } else {
+    g.cr[i] = sr + rr + fr;
+    g.cg[i] = sg + rg + fg;
+    g.cb[i] = sb + rb + fb;
+  }
+}
+
+// Canvas::save quantisation (src/canvas.rs:60-62): ceil(clamp(c * 255, 0, 255)); NaN -> 0
+DEV uint8_t quantise(double c) {
+  double v = c * 255.0;
+  if (v < 0.0) v = 0.0;
+  else if (v > 255.0) v = 255.0;
+  v = ceil(v);
+  return (v == v) ? (uint8_t)v : (uint8_t)0;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+    k_output_image(GenView g, uint32_t n, CameraDev cam, const uint32_t* tiles, uint32_t tiles_x, uint8_t* rgb8,
+                   double* rgb64, int32_t* hit_leaf) {
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x, y;
+  if (!ray_pixel(tiles, tiles_x, cam, i, x, y)) return;
+  size_t p = (size_t)y * cam.hsize + x;
+  double r = g.cr[i], gg = g.cg[i], b = g.cb[i];
+  if (rgb64) {
+    rgb64[p * 3 + 0] = r; rgb64[p * 3 + 1] = gg; rgb64[p * 3 + 2] = b;
+  }
+  if (rgb8) {
+    rgb8[p * 3 + 0] = quantise(r); rgb8[p * 3 + 1] = quantise(gg); rgb8[p * 3 + 2] = quantise(b);
+  }
+  if (hit_leaf) hit_leaf[p] = g.leaf[i];
+}
+
+__global__ void __launch_bounds__(BLOCK)
+    k_output_rays(GenView g, uint32_t n, double* rgb, int32_t* leaf, double* t) {
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  if (rgb) {
+    rgb[(size_t)i * 3 + 0] = g.cr[i]; rgb[(size_t)i * 3 + 1] = g.cg[i]; rgb[(size_t)i * 3 + 2] = g.cb[i];
+  }
+  int l = g.leaf[i];
+  if (leaf) leaf[i] = l;
+  if (t) t[i] = l >= 0 ? g.t[i] : NAN;
+}
+
+// World::is_shadowed for caller-supplied points.
+template <int STACK>
+__global__ void __launch_bounds__(BLOCK) k_points_shadowed(SceneDev S, uint32_t n, const double* pts, uint8_t* out) {
+  __shared__ uint32_t lds[STACK * BLOCK];
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  LdsStack<STACK, BLOCK> st;
+  st.init(lds);
+  Counters cnt = {0, 0, 0, 0};
+  V3 p = v3(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]);
+  V3 v = v3(S.light_position[0], S.light_position[1], S.light_position[2]) - p;
+  ShadowQuery Q;
+  Q.distance = magnitude(v);
+  Q.found = false;
+  Ray ray{p, normalize(v)};
+  traverse<ShadowQuery, LdsStack<STACK, BLOCK>, false>(S, ray, Q, st, cnt);
+  out[i] = Q.found ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_pixel_rays(CameraDev cam, uint32_t n, const uint32_t* xy, double* rays6) {
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  Ray r = camera_ray(cam, xy[i * 2], xy[i * 2 + 1]);
+  double* o = rays6 + (size_t)i * 6;
+  o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z;
+  o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_export_rays(GenView g, uint32_t n, double* rays6) {
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double* r = rays6 + (size_t)i * 6;
+  r[0] = g.ox[i]; r[1] = g.oy[i]; r[2] = g.oz[i];
+  r[3] = g.dx[i]; r[4] = g.dy[i]; r[5] = g.dz[i];
+}
+
+// ---------------------------------------------------------------------------
+// host side: scene object
+// ---------------------------------------------------------------------------
+namespace {
+
+struct GenBuf {
+  void* slab = nullptr;
+  size_t capacity = 0;
+  GenView view;
+};
+
+constexpr int N_DOUBLE_ARRAYS = 26;
+constexpr int N_U32_ARRAYS = 5;
+
+size_t gen_bytes(size_t cap) {
+  size_t c = (cap + 63) & ~(size_t)63;
+  return c * (N_DOUBLE_ARRAYS * sizeof(double) + N_U32_ARRAYS * sizeof(uint32_t));
+}
+
+void carve(GenBuf& b) {
+  size_t c = (b.capacity + 63) & ~(size_t)63;
+  double* d = (double*)b.slab;
+  GenView& v = b.view;
+  double** dptr[N_DOUBLE_ARRAYS] = {&v.ox, &v.oy, &v.oz, &v.dx, &v.dy, &v.dz, &v.t,  &v.u,  &v.v,  &v.n1,
+                                    &v.n2, &v.px, &v.py, &v.pz, &v.ar, &v.ag, &v.ab, &v.lr, &v.lg, &v.lb,
+                                    &v.cr, &v.cg, &v.cb, &v.reflective, &v.transparency, &v.reflectance};
+  for (int k = 0; k < N_DOUBLE_ARRAYS; k++) *dptr[k] = d + (size_t)k * c;
+  uint32_t* u = (uint32_t*)(d + (size_t)N_DOUBLE_ARRAYS * c);
+  v.leaf = (int32_t*)u;
+  v.child_reflect = u + c;
+  v.child_refract = u + 2 * c;
+  v.flags = u + 3 * c;
+  v.shadow_queue = u + 4 * c;
+}
+
+}  // namespace
+
+struct rt_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  SceneDev dev{};
+  std::vector<void*> allocs;
+  uint64_t scene_bytes = 0;
+  double build_seconds = 0;
+  int stack_need = 1;
+  int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
+  GenBuf gens[MAX_GENERATIONS];
+  uint32_t* d_counts = nullptr;             // [gen][2]: shadow queue length, next generation length
+  unsigned long long* d_stats = nullptr;    // 8 counters
+  uint32_t* h_counts = nullptr;             // pinned mirror
+  unsigned long long* h_stats = nullptr;
+  uint32_t* d_tiles = nullptr;
+  size_t tiles_capacity = 0;
+  std::vector<uint32_t> h_tiles;
+  hipEvent_t ev[4 * MAX_GENERATIONS] = {};
+  // staging for the host-buffer entry points
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+};
+
+namespace {
+
+template <class T>
+int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
+  *out = nullptr;
+  if (v.empty()) return RT_OK;
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+  s->allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  s->scene_bytes += v.size() * sizeof(T);
+  *out = (const T*)p;
+  return RT_OK;
+}
+
+bool affine(const double* m) {
+  return fabs(m[12]) < 1e-9 && fabs(m[13]) < 1e-9 && fabs(m[14]) < 1e-9 && fabs(m[15] - 1.0) < 1e-9;
+}
+bool is_identity(const double* m) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++)
+      if (m[r * 4 + c] != (r == c ? 1.0 : 0.0)) return false;  // -0.0 == 0.0
+  return true;
+}
+
+void box_of_points(const double* fwd, const double (*pts)[3], int n, double lo[3], double hi[3]) {
+  for (int a = 0; a < 3; a++) {
+    lo[a] = INFINITY;
+    hi[a] = -INFINITY;
+  }
+  for (int i = 0; i < n; i++) {
+    for (int a = 0; a < 3; a++) {
+      double v = fwd[a * 4 + 0] * pts[i][0] + fwd[a * 4 + 1] * pts[i][1] + fwd[a * 4 + 2] * pts[i][2] + fwd[a * 4 + 3];
+      lo[a] = fmin(lo[a], v);
+      hi[a] = fmax(hi[a], v);
+    }
+  }
+  // Pad: the reference finds hits by rounded object-space arithmetic, so a hit can sit a few
+  // ulps outside the exact shape; the pad also absorbs the rounding of the slab test.
+  for (int a = 0; a < 3; a++) {
+    double pad = 1e-7 * (fabs(lo[a]) + fabs(hi[a]) + (hi[a] - lo[a])) + 1e-9;
+    lo[a] -= pad;
+    hi[a] += pad;
+  }
+}
+
+// World-space box of a leaf, or false when it has to be tested for every ray.
+bool leaf_box(const rt_leaf& L, const rt_xform& X, const rt_triangle* tri, double lo[3], double hi[3]) {
+  const double* f = X.fwd;
+  double scale = 0;
+  for (int c = 0; c < 3; c++)
+    scale = fmax(scale, sqrt(f[c] * f[c] + f[4 + c] * f[4 + c] + f[8 + c] * f[8 + c]));
+  double x0, x1, y0, y1;
+  switch (L.type) {
+    case RT_SPHERE: x0 = y0 = -1; x1 = y1 = 1; break;
+    case RT_CUBE:
+      // A cube treats a ray whose object-space direction component is below 1e-4 as parallel to
+      // that slab (src/shape.rs:1372-1377); for a very large cube that widens its silhouette by
+      // far more than any pad, so such cubes are tested for every ray.
+      if (scale > 100.0) return false;
+      x0 = y0 = -1 - 1e-3; x1 = y1 = 1 + 1e-3;
+      break;
+    case RT_CYLINDER:
+      if (!std::isfinite(L.minimum) || !std::isfinite(L.maximum)) return false;
+      x0 = -1; x1 = 1; y0 = L.minimum; y1 = L.maximum;
+      break;
+    case RT_CONE: {
+      if (!std::isfinite(L.minimum) || !std::isfinite(L.maximum) || scale > 100.0) return false;
+      double r = fmax(fabs(L.minimum), fabs(L.maximum));
+      x0 = -r; x1 = r; y0 = L.minimum; y1 = L.maximum;
+      break;
+    }
+    case RT_TRIANGLE:
+    case RT_SMOOTH_TRIANGLE: {
+      double pts[3][3];
+      for (int a = 0; a < 3; a++) {
+        pts[0][a] = tri->p1[a];
+        pts[1][a] = tri->p1[a] + tri->e1[a];
+        pts[2][a] = tri->p1[a] + tri->e2[a];
+      }
+      box_of_points(f, pts, 3, lo, hi);
+      return true;
+    }
+    default: return false;  // plane
+  }
+  double pts[8][3];
+  for (int k = 0; k < 8; k++) {
+    pts[k][0] = (k & 1) ? x1 : x0;
+    pts[k][1] = (k & 2) ? y1 : y0;
+    pts[k][2] = (k & 4) ? x1 : x0;
+  }
+  box_of_points(f, pts, 8, lo, hi);
+  return true;
+}
+
+void copy3x4(double* dst, const double* src16) { memcpy(dst, src16, 12 * sizeof(double)); }
+
+struct SceneBuild {
+  const rt_scene_desc* d;
+  BvhBuilder bvh;
+  std::vector<std::vector<int>> gate_children, gate_leaves;
+  std::vector<int> top_gates, top_leaves;
+  std::vector<Gate> gates;
+  std::vector<QuadPrim> quad_src, unbounded;
+  std::vector<TriIsect> tri_src;
+  std::vector<int> tri_xform;  // device xform index or -1 (identity)
+  int stack_need = 1;
+
+  QuadPrim make_quad(int li) const {
+    const rt_leaf& L = d->leaves[li];
+    QuadPrim q{};
+    copy3x4(q.m, d->xforms[L.xform].ray_inv);
+    q.minimum = L.minimum;
+    q.maximum = L.maximum;
+    q.type = L.type;
+    q.closed = L.closed;
+    q.leaf = li;
+    q.gate = L.gate;
+    return q;
+  }
+
+  // Items of the leaves directly under one group (or the top level).
+  void leaf_items(const std::vector<int>& leaves, std::vector<BuildItem>& items) {
+    for (int li : leaves) {
+      const rt_leaf& L = d->leaves[li];
+      if (L.type == RT_EMPTY) continue;  // never intersects (src/shape.rs:789)
+      const rt_xform& X = d->xforms[L.xform];
+      BuildItem it{};
+      bool tri = L.type == RT_TRIANGLE || L.type == RT_SMOOTH_TRIANGLE;
+      if (!leaf_box(L, X, tri ? &d->triangles[L.tri] : nullptr, it.lo, it.hi)) {
+        unbounded.push_back(make_quad(li));
+        continue;
+      }
+      if (tri) {
+        const rt_triangle& T = d->triangles[L.tri];
+        TriIsect ti{};
+        for (int a = 0; a < 3; a++) {
+          ti.p1[a] = T.p1[a];
+          ti.e1[a] = T.e1[a];
+          ti.e2[a] = T.e2[a];
+        }
+        ti.leaf = li;
+        ti.xform = is_identity(X.ray_inv) ? -1 : L.xform;
+        it.kind = KIND_TRI;
+        it.index = (uint32_t)tri_src.size();
+        tri_src.push_back(ti);
+      } else {
+        it.kind = KIND_QUAD;
+        it.index = (uint32_t)quad_src.size();
+        quad_src.push_back(make_quad(li));
+      }
+      items.push_back(it);
+    }
+  }
+
+  // Builds the subtree of gate gi; returns depth needed below it and its box.
+  int build_gate(int gi, BuildItem* out_item, bool* has_item) {
+    std::vector<BuildItem> items;
+    int child_depth = 0;
+    for (int c : gate_children[gi]) {
+      BuildItem it{};
+      bool ok = false;
+      int dep = build_gate(c, &it, &ok);
+      if (ok) {
+        items.push_back(it);
+        child_depth = std::max(child_depth, dep);
+      }
+    }
+    leaf_items(gate_leaves[gi], items);
+    const rt_gate& G = d->gates[gi];
+    Gate& g = gates[gi];
+    copy3x4(g.m, G.to_local);
+    for (int a = 0; a < 3; a++) {
+      g.bmin[a] = G.bmin[a];
+      g.bmax[a] = G.bmax[a];
+    }
+    g.parent = G.parent;
+    double lo[3], hi[3];
+    bvh.max_depth = 0;
+    g.root = bvh.build(items, lo, hi);
+    int own = bvh.max_depth;
+    *has_item = g.root != REF_NONE;
+    if (*has_item) {
+      out_item->kind = KIND_GATE;
+      out_item->index = (uint32_t)gi;
+      for (int a = 0; a < 3; a++) {
+        out_item->lo[a] = lo[a];
+        out_item->hi[a] = hi[a];
+      }
+    }
+    return own + 1 + child_depth;
+  }
+};
+
+int pick_stack(int need) {
+  if (need <= 16) return 16;
+  if (need <= 32) return 32;
+  if (need <= 48) return 48;
+  return 64;
+}
+
+}  // namespace
+
+extern "C" const char* rt_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int rt_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return n;
+}
+
+extern "C" void rt_scene_destroy(rt_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (void* p : s->allocs) (void)hipFree(p);
+  for (GenBuf& g : s->gens)
+    if (g.slab) (void)hipFree(g.slab);
+  if (s->d_counts) (void)hipFree(s->d_counts);
+  if (s->d_stats) (void)hipFree(s->d_stats);
+  if (s->h_counts) (void)hipHostFree(s->h_counts);
+  if (s->h_stats) (void)hipHostFree(s->h_stats);
+  if (s->d_tiles) (void)hipFree(s->d_tiles);
+  if (s->stage) (void)hipFree(s->stage);
+  for (hipEvent_t e : s->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
+  // ---- validate
+  if (d->n_leaves < 0 || d->n_gates < 0 || d->n_xforms < 0 || d->n_triangles < 0 || d->n_materials < 0 ||
+      d->n_patterns < 0)
+    return fail(RT_ERR_INVALID, "negative count in scene description");
+  for (int i = 0; i < d->n_xforms; i++) {
+    if (!affine(d->xforms[i].ray_inv) || !affine(d->xforms[i].full_inv) || !affine(d->xforms[i].fwd))
+      return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) shape transform: last row must be 0 0 0 1");
+  }
+  for (int i = 0; i < d->n_gates; i++) {
+    if (!affine(d->gates[i].to_local)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) group transform");
+    if (d->gates[i].parent >= i || d->gates[i].parent < -1)
+      return fail(RT_ERR_INVALID, "gate parent must precede its children");
+  }
+  for (int i = 0; i < d->n_patterns; i++) {
+    const rt_pattern& p = d->patterns[i];
+    if (!affine(p.inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) pattern transform");
+    if (p.type < RT_PAT_NULL || p.type > RT_PAT_BLEND) return fail(RT_ERR_INVALID, "unknown pattern type");
+    if (p.type == RT_PAT_BLEND && (p.first < 0 || p.first >= d->n_patterns || p.second < 0 || p.second >= d->n_patterns))
+      return fail(RT_ERR_INVALID, "blend pattern operand out of range");
+  }
+  for (int i = 0; i < d->n_materials; i++)
+    if (d->materials[i].pattern < -1 || d->materials[i].pattern >= d->n_patterns)
+      return fail(RT_ERR_INVALID, "material pattern index out of range");
+  for (int i = 0; i < d->n_leaves; i++) {
+    const rt_leaf& L = d->leaves[i];
+    if (L.type < RT_EMPTY || L.type > RT_SMOOTH_TRIANGLE) return fail(RT_ERR_INVALID, "unknown leaf type");
+    if (L.material < 0 || L.material >= d->n_materials) return fail(RT_ERR_INVALID, "leaf material out of range");
+    if (L.xform < 0 || L.xform >= d->n_xforms) return fail(RT_ERR_INVALID, "leaf xform out of range");
+    if (L.gate < -1 || L.gate >= d->n_gates) return fail(RT_ERR_INVALID, "leaf gate out of range");
+    bool tri = L.type == RT_TRIANGLE || L.type == RT_SMOOTH_TRIANGLE;
+    if (tri && (L.tri < 0 || L.tri >= d->n_triangles)) return fail(RT_ERR_INVALID, "leaf triangle out of range");
+  }
+  if ((uint64_t)d->n_triangles > MAX_RUN_FIRST) return fail(RT_ERR_UNSUPPORTED, "too many triangles");
+
+  HIP_TRY(hipSetDevice(device));
+  s->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+
+  // ---- acceleration structure
+  auto t0 = std::chrono::steady_clock::now();
+  SceneBuild b;
+  b.d = d;
+  b.gate_children.resize(d->n_gates);
+  b.gate_leaves.resize(d->n_gates);
+  b.gates.resize(d->n_gates);
+  for (int i = 0; i < d->n_gates; i++) {
+    if (d->gates[i].parent < 0) b.top_gates.push_back(i);
+    else b.gate_children[d->gates[i].parent].push_back(i);
+  }
+  for (int i = 0; i < d->n_leaves; i++) {
+    if (d->leaves[i].gate < 0) b.top_leaves.push_back(i);
+    else b.gate_leaves[d->leaves[i].gate].push_back(i);
+  }
+  std::vector<BuildItem> items;
+  int child_depth = 0;
+  for (int gi : b.top_gates) {
+    BuildItem it{};
+    bool ok = false;
+    int dep = b.build_gate(gi, &it, &ok);
+    if (ok) {
+      items.push_back(it);
+      child_depth = std::max(child_depth, dep);
+    }
+  }
+  b.leaf_items(b.top_leaves, items);
+  double lo[3], hi[3];
+  b.bvh.max_depth = 0;
+  uint32_t root = b.bvh.build(items, lo, hi);
+  s->stack_need = b.bvh.max_depth + 1 + child_depth + 1;
+  if (s->stack_need > TRAVERSAL_STACK)
+    return fail(RT_ERR_UNSUPPORTED, "scene hierarchy is deeper than the traversal stack");
+
+  std::vector<TriIsect> tris(b.bvh.tri_order.size());
+  for (size_t i = 0; i < tris.size(); i++) tris[i] = b.tri_src[b.bvh.tri_order[i]];
+  std::vector<QuadPrim> quads(b.bvh.quad_order.size());
+  for (size_t i = 0; i < quads.size(); i++) quads[i] = b.quad_src[b.bvh.quad_order[i]];
+  s->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+  // ---- shading tables
+  std::vector<LeafShade> leaves(d->n_leaves);
+  for (int i = 0; i < d->n_leaves; i++) {
+    const rt_leaf& L = d->leaves[i];
+    LeafShade& o = leaves[i];
+    o.type = L.type; o.closed = L.closed; o.material = L.material; o.xform = L.xform;
+    o.tri = L.tri; o.pad = 0; o.minimum = L.minimum; o.maximum = L.maximum;
+    for (int a = 0; a < 3; a++) o.plane_normal[a] = L.plane_normal[a];
+  }
+  std::vector<XformDev> xforms(d->n_xforms);
+  for (int i = 0; i < d->n_xforms; i++) {
+    copy3x4(xforms[i].ray_inv, d->xforms[i].ray_inv);
+    copy3x4(xforms[i].full_inv, d->xforms[i].full_inv);
+  }
+  std::vector<TriShade> tri_shade(d->n_triangles);
+  for (int i = 0; i < d->n_triangles; i++) {
+    const rt_triangle& T = d->triangles[i];
+    for (int a = 0; a < 3; a++) {
+      tri_shade[i].normal[a] = T.normal[a];
+      tri_shade[i].n1[a] = T.n1[a];
+      tri_shade[i].n2[a] = T.n2[a];
+      tri_shade[i].n3[a] = T.n3[a];
+    }
+  }
+  std::vector<MaterialDev> mats(d->n_materials);
+  bool any_reflect = false, any_refract = false;
+  for (int i = 0; i < d->n_materials; i++) {
+    const rt_material& M = d->materials[i];
+    MaterialDev& o = mats[i];
+    for (int a = 0; a < 3; a++) o.color[a] = M.color[a];
+    o.ambient = M.ambient; o.diffuse = M.diffuse; o.specular = M.specular; o.shininess = M.shininess;
+    o.reflective = M.reflective; o.refractive_index = M.refractive_index; o.transparency = M.transparency;
+    o.pattern = M.pattern;
+    bool refl = !(fabs(M.reflective - 0.0) < FEQ_EPSILON);      // world.rs:151
+    bool refr = !(fabs(M.transparency - 0.0) < FEQ_EPSILON);    // world.rs:190
+    bool schlick = M.reflective > 0.0 && M.transparency > 0.0;  // world.rs:237
+    o.flags = (refl ? 1 : 0) | (refr ? 2 : 0) | (schlick ? 4 : 0) | ((refr || schlick) ? 8 : 0);
+    any_reflect |= refl;
+    any_refract |= refr;
+  }
+  s->max_children = (any_reflect ? 1 : 0) + (any_refract ? 1 : 0);
+  std::vector<PatternDev> pats(d->n_patterns);
+  for (int i = 0; i < d->n_patterns; i++) {
+    const rt_pattern& P = d->patterns[i];
+    pats[i].type = P.type; pats[i].first = P.first; pats[i].second = P.second; pats[i].pad = 0;
+    copy3x4(pats[i].inv, P.inv);
+    for (int a = 0; a < 3; a++) {
+      pats[i].a[a] = P.a[a];
+      pats[i].b[a] = P.b[a];
+    }
+  }
+
+  // ---- upload
+  int rc;
+  if ((rc = upload(s, b.bvh.nodes, &s->dev.nodes))) return rc;
+  if ((rc = upload(s, tris, &s->dev.tris))) return rc;
+  if ((rc = upload(s, quads, &s->dev.quads))) return rc;
+  if ((rc = upload(s, b.gates, &s->dev.gates))) return rc;
+  if ((rc = upload(s, b.unbounded, &s->dev.unbounded))) return rc;
+  if ((rc = upload(s, leaves, &s->dev.leaves))) return rc;
+  if ((rc = upload(s, xforms, &s->dev.xforms))) return rc;
+  if ((rc = upload(s, tri_shade, &s->dev.tri_shade))) return rc;
+  if ((rc = upload(s, mats, &s->dev.materials))) return rc;
+  if ((rc = upload(s, pats, &s->dev.patterns))) return rc;
+  s->dev.root = root;
+  s->dev.n_unbounded = (int32_t)b.unbounded.size();
+  s->dev.n_leaves = d->n_leaves;
+  for (int a = 0; a < 3; a++) {
+    s->dev.light_intensity[a] = d->light.intensity[a];
+    s->dev.light_position[a] = d->light.position[a];
+  }
+
+  HIP_TRY(hipMalloc((void**)&s->d_counts, MAX_GENERATIONS * 2 * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc((void**)&s->d_stats, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_counts, MAX_GENERATIONS * 2 * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_stats, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
+  return RT_OK;
+}
+
+extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+  if (!desc || !out) return fail(RT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  rt_scene* s = new (std::nothrow) rt_scene();
+  if (!s) return fail(RT_ERR_NOMEM, "out of host memory");
+  int rc;
+  try {
+    rc = scene_create_impl(desc, device, s);
+  } catch (const std::bad_alloc&) {
+    rc = fail(RT_ERR_NOMEM, "out of host memory while building the scene");
+  } catch (const std::exception& e) {
+    rc = fail(RT_ERR_INVALID, e.what());
+  }
+  if (rc != RT_OK) {
+    std::string keep = g_last_error;
+    rt_scene_destroy(s);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = s;
+  return RT_OK;
+}
+
+extern "C" int rt_scene_footprint(const rt_scene* s, uint64_t* scene_bytes, double* build_seconds) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  if (scene_bytes) *scene_bytes = s->scene_bytes;
+  if (build_seconds) *build_seconds = s->build_seconds;
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host side: the generation pipeline
+// ---------------------------------------------------------------------------
+namespace {
+
+int ensure_gen(rt_scene* s, int g, size_t cap) {
+  GenBuf& b = s->gens[g];
+  if (cap == 0) cap = 64;
+  if (b.capacity >= cap) return RT_OK;
+  if (b.slab) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipFree(b.slab));
+    b.slab = nullptr;
+    b.capacity = 0;
+  }
+  HIP_TRY(hipMalloc(&b.slab, gen_bytes(cap)));
+  b.capacity = cap;
+  carve(b);
+  return RT_OK;
+}
+
+inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
+
+template <bool COUNT>
+void launch_trace(rt_scene* s, const GenView& g, uint32_t n) {
+  dim3 grid(blocks_for(n)), block(BLOCK);
+  switch (pick_stack(s->stack_need)) {
+    case 16: hipLaunchKernelGGL((k_trace<16, COUNT>), grid, block, 0, s->stream, s->dev, g, n, s->d_stats); break;
+    case 32: hipLaunchKernelGGL((k_trace<32, COUNT>), grid, block, 0, s->stream, s->dev, g, n, s->d_stats); break;
+    case 48: hipLaunchKernelGGL((k_trace<48, COUNT>), grid, block, 0, s->stream, s->dev, g, n, s->d_stats); break;
+    default: hipLaunchKernelGGL((k_trace<64, COUNT>), grid, block, 0, s->stream, s->dev, g, n, s->d_stats); break;
+  }
+}
+template <bool COUNT>
+void launch_shadow(rt_scene* s, const GenView& g, uint32_t n, const uint32_t* count) {
+  dim3 grid(blocks_for(n)), block(BLOCK);
+  switch (pick_stack(s->stack_need)) {
+    case 16: hipLaunchKernelGGL((k_shadow<16, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats); break;
+    case 32: hipLaunchKernelGGL((k_shadow<32, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats); break;
+    case 48: hipLaunchKernelGGL((k_shadow<48, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats); break;
+    default: hipLaunchKernelGGL((k_shadow<64, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats); break;
+  }
+}
+
+// Runs trace/shade/shadow over generation 0 (already filled with n0 rays) and
+// its descendants, then resolves colours back into generation 0.
+int run_generations(rt_scene* s, uint32_t n0, int remaining0, uint32_t flags, bool shade, rt_stats* stats) {
+  const bool count = (flags & RT_FLAG_COUNTERS) != 0;
+  HIP_TRY(hipMemsetAsync(s->d_counts, 0, MAX_GENERATIONS * 2 * sizeof(uint32_t), s->stream));
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, 8 * sizeof(unsigned long long), s->stream));
+  uint32_t n[MAX_GENERATIONS + 1] = {0};
+  n[0] = n0;
+  int last = 0;
+  int ngen_max = remaining0 < 0 ? 0 : remaining0;
+  if (ngen_max > RECURSION_DEPTH) ngen_max = RECURSION_DEPTH;
+  for (int g = 0; g <= ngen_max && n[g] > 0; g++) {
+    last = g;
+    const GenView& cur = s->gens[g].view;
+    HIP_TRY(hipEventRecord(s->ev[g * 4 + 0], s->stream));
+    if (count) launch_trace<true>(s, cur, n[g]);
+    else launch_trace<false>(s, cur, n[g]);
+    HIP_TRY(hipEventRecord(s->ev[g * 4 + 1], s->stream));
+    if (!shade) break;
+    int remaining = remaining0 - g;
+    uint64_t next_cap64 = remaining > 0 ? (uint64_t)n[g] * (uint64_t)s->max_children : 0;
+    if (next_cap64 > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "too many secondary rays for one generation");
+    int rc = ensure_gen(s, g + 1 < MAX_GENERATIONS ? g + 1 : g, (size_t)next_cap64);
+    if (rc) return rc;
+    const GenView& nxt = s->gens[g + 1 < MAX_GENERATIONS ? g + 1 : g].view;
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(n[g])), dim3(BLOCK), 0, s->stream, s->dev, cur, n[g], nxt,
+                       (uint32_t)next_cap64, remaining, s->d_counts + g * 2, s->d_counts + g * 2 + 1, s->d_stats);
+    HIP_TRY(hipEventRecord(s->ev[g * 4 + 2], s->stream));
+    if (count) launch_shadow<true>(s, cur, n[g], s->d_counts + g * 2);
+    else launch_shadow<false>(s, cur, n[g], s->d_counts + g * 2);
+    HIP_TRY(hipEventRecord(s->ev[g * 4 + 3], s->stream));
+    if (remaining > 0 && s->max_children > 0) {
+      HIP_TRY(hipMemcpyAsync(s->h_counts + g * 2, s->d_counts + g * 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      n[g + 1] = std::min<uint32_t>(s->h_counts[g * 2 + 1], (uint32_t)next_cap64);
+    }
+  }
+  if (shade) {
+    for (int g = last - 1; g >= 0; g--)
+      hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n[g])), dim3(BLOCK), 0, s->stream, s->gens[g].view, n[g],
+                         s->gens[g + 1].view);
+  }
+  HIP_TRY(hipGetLastError());
+  if (stats) {
+    HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    stats->node_visits = s->h_stats[0];
+    stats->tri_tests = s->h_stats[1];
+    stats->quadric_tests = s->h_stats[2];
+    stats->gate_tests = s->h_stats[3];
+    stats->shaded_hits = s->h_stats[4];
+    stats->shadow = s->h_stats[4];
+    stats->reflect = s->h_stats[5];
+    stats->refract = s->h_stats[6];
+    stats->trace_ms = 0;
+    stats->shadow_ms = 0;
+    stats->trace_launches = 0;
+    stats->shadow_launches = 0;
+    for (int g = 0; g <= last; g++) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, s->ev[g * 4 + 0], s->ev[g * 4 + 1]));
+      stats->trace_ms += ms;
+      stats->trace_launches++;
+      if (shade) {
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev[g * 4 + 2], s->ev[g * 4 + 3]));
+        stats->shadow_ms += ms;
+        stats->shadow_launches++;
+      }
+    }
+  }
+  return RT_OK;
+}
+
+CameraDev camera_dev(const rt_camera* c) {
+  CameraDev cd;
+  cd.hsize = c->hsize;
+  cd.vsize = c->vsize;
+  cd.half_width = c->half_width;
+  cd.half_height = c->half_height;
+  cd.pixel_size = c->pixel_size;
+  copy3x4(cd.inv, c->inv);
+  return cd;
+}
+
+int stage_reserve(rt_scene* s, size_t bytes) {
+  if (s->stage_bytes >= bytes) return RT_OK;
+  if (s->stage) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipFree(s->stage));
+    s->stage = nullptr;
+    s->stage_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&s->stage, bytes));
+  s->stage_bytes = bytes;
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_parts, uint32_t flags,
+                         uint8_t* rgb8_dev, double* rgb64_dev, int32_t* hit_leaf_dev, rt_stats* stats) {
+  if (!s || !camera) return fail(RT_ERR_INVALID, "null argument");
+  if (n_parts < 1 || part < 0 || part >= n_parts) return fail(RT_ERR_INVALID, "part must lie in [0, n_parts)");
+  if (camera->hsize == 0 || camera->vsize == 0) return fail(RT_ERR_INVALID, "empty canvas");
+  if (!affine(camera->inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) camera transform");
+  auto w0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(s->device));
+  uint32_t tiles_x = (camera->hsize + TILE - 1) / TILE, tiles_y = (camera->vsize + TILE - 1) / TILE;
+  s->h_tiles.clear();
+  for (uint32_t ty = 0; ty < tiles_y; ty++)
+    for (uint32_t tx = 0; tx < tiles_x; tx++)
+      if ((int)((tx + ty) % (uint32_t)n_parts) == part) s->h_tiles.push_back(ty * tiles_x + tx);
+  uint64_t n64 = (uint64_t)s->h_tiles.size() * TILE_PIXELS;
+  if (n64 > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "canvas part exceeds 2^32 rays");
+  uint32_t n = (uint32_t)n64;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return RT_OK;
+  if (s->tiles_capacity < s->h_tiles.size()) {
+    if (s->d_tiles) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      HIP_TRY(hipFree(s->d_tiles));
+      s->d_tiles = nullptr;
+    }
+    HIP_TRY(hipMalloc((void**)&s->d_tiles, s->h_tiles.size() * sizeof(uint32_t)));
+    s->tiles_capacity = s->h_tiles.size();
+  }
+  HIP_TRY(hipMemcpyAsync(s->d_tiles, s->h_tiles.data(), s->h_tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                         s->stream));
+  int rc = ensure_gen(s, 0, n);
+  if (rc) return rc;
+  CameraDev cam = camera_dev(camera);
+  hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, n, cam, s->d_tiles,
+                     tiles_x);
+  rc = run_generations(s, n, RECURSION_DEPTH, flags, true, stats);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_output_image, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, n, cam,
+                     s->d_tiles, tiles_x, rgb8_dev, rgb64_dev, hit_leaf_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (stats) {
+    uint64_t valid = 0;
+    for (uint32_t t : s->h_tiles) {
+      uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * TILE;
+      uint32_t w = std::min<uint32_t>(TILE, camera->hsize - x0), h = std::min<uint32_t>(TILE, camera->vsize - y0);
+      valid += (uint64_t)w * h;
+    }
+    stats->primary = valid;
+    stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  }
+  return RT_OK;
+}
+
+extern "C" int rt_render_host(rt_scene* s, const rt_camera* camera, int part, int n_parts, uint32_t flags,
+                              uint8_t* rgb8, double* rgb64, int32_t* hit_leaf, rt_stats* stats) {
+  if (!s || !camera) return fail(RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  size_t np = (size_t)camera->hsize * camera->vsize;
+  size_t b8 = rgb8 ? np * 3 : 0, b64 = rgb64 ? np * 3 * sizeof(double) : 0, bl = hit_leaf ? np * sizeof(int32_t) : 0;
+  size_t off64 = (b8 + 255) & ~(size_t)255, offl = (off64 + b64 + 255) & ~(size_t)255;
+  int rc = stage_reserve(s, offl + bl + 256);
+  if (rc) return rc;
+  char* base = (char*)s->stage;
+  HIP_TRY(hipMemsetAsync(base, 0, offl + bl, s->stream));
+  if (hit_leaf) HIP_TRY(hipMemsetAsync(base + offl, 0xFF, bl, s->stream));
+  rc = rt_render(s, camera, part, n_parts, flags, rgb8 ? (uint8_t*)base : nullptr,
+                 rgb64 ? (double*)(base + off64) : nullptr, hit_leaf ? (int32_t*)(base + offl) : nullptr, stats);
+  if (rc) return rc;
+  if (rgb8) HIP_TRY(hipMemcpy(rgb8, base, b8, hipMemcpyDeviceToHost));
+  if (rgb64) HIP_TRY(hipMemcpy(rgb64, base + off64, b64, hipMemcpyDeviceToHost));
+  if (hit_leaf) HIP_TRY(hipMemcpy(hit_leaf, base + offl, bl, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+extern "C" int rt_ray_for_pixel(rt_scene* s, const rt_camera* camera, uint64_t n, const uint32_t* xy,
+                                double* rays6) {
+  if (!s || !camera || (n && (!xy || !rays6))) return fail(RT_ERR_INVALID, "null argument");
+  if (!affine(camera->inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) camera transform");
+  HIP_TRY(hipSetDevice(s->device));
+  if (n == 0) return RT_OK;
+  if (n > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "too many pixels in one call");
+  int rc = ensure_gen(s, 0, (size_t)n);
+  if (rc) return rc;
+  rc = stage_reserve(s, n * 6 * sizeof(double) + n * 2 * sizeof(uint32_t));
+  if (rc) return rc;
+  double* d_rays = (double*)s->stage;
+  uint32_t* d_xy = (uint32_t*)(d_rays + n * 6);
+  HIP_TRY(hipMemcpyAsync(d_xy, xy, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_pixel_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, camera_dev(camera), (uint32_t)n,
+                     d_xy, d_rays);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rays6, d_rays, n * 6 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RT_OK;
+}
+
+static int load_user_rays(rt_scene* s, uint64_t n, const double* rays6) {
+  if (n > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "too many rays in one call");
+  int rc = ensure_gen(s, 0, (size_t)n);
+  if (rc) return rc;
+  rc = stage_reserve(s, n * 6 * sizeof(double) + n * 16);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s->stage, rays6, n * 6 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_load_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, (uint32_t)n,
+                     (const double*)s->stage);
+  return RT_OK;
+}
+
+extern "C" int rt_color_at(rt_scene* s, uint64_t n, const double* rays6, int remaining, uint32_t flags, double* rgb,
+                           int32_t* leaf, rt_stats* stats) {
+  if (!s || (n && (!rays6 || !rgb))) return fail(RT_ERR_INVALID, "null argument");
+  if (remaining < 0) return fail(RT_ERR_INVALID, "remaining must be >= 0");
+  if (remaining > RECURSION_DEPTH) return fail(RT_ERR_UNSUPPORTED, "remaining above the reference's depth of 5");
+  HIP_TRY(hipSetDevice(s->device));
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return RT_OK;
+  auto w0 = std::chrono::steady_clock::now();
+  int rc = load_user_rays(s, n, rays6);
+  if (rc) return rc;
+  rc = run_generations(s, (uint32_t)n, remaining, flags, true, stats);
+  if (rc) return rc;
+  // rays6 staging is no longer needed: reuse the buffer for the results
+  double* d_rgb = (double*)s->stage;
+  int32_t* d_leaf = (int32_t*)(d_rgb + n * 3);
+  hipLaunchKernelGGL(k_output_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, (uint32_t)n,
+                     d_rgb, d_leaf, (double*)nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rgb, d_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (leaf) HIP_TRY(hipMemcpyAsync(leaf, d_leaf, n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (stats) {
+    stats->primary = n;
+    stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  }
+  return RT_OK;
+}
+
+extern "C" int rt_intersect_hit(rt_scene* s, uint64_t n, const double* rays6, double* t, int32_t* leaf) {
+  if (!s || (n && (!rays6 || !t || !leaf))) return fail(RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (n == 0) return RT_OK;
+  int rc = load_user_rays(s, n, rays6);
+  if (rc) return rc;
+  rc = run_generations(s, (uint32_t)n, 0, 0, false, nullptr);
+  if (rc) return rc;
+  double* d_t = (double*)s->stage;
+  int32_t* d_leaf = (int32_t*)(d_t + n);
+  hipLaunchKernelGGL(k_output_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, (uint32_t)n,
+                     (double*)nullptr, d_leaf, d_t);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(leaf, d_leaf, n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RT_OK;
+}
+
+extern "C" int rt_is_shadowed(rt_scene* s, uint64_t n, const double* points3, uint8_t* shadowed) {
+  if (!s || (n && (!points3 || !shadowed))) return fail(RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (n == 0) return RT_OK;
+  if (n > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "too many points in one call");
+  int rc = stage_reserve(s, n * 3 * sizeof(double) + n + 256);
+  if (rc) return rc;
+  double* d_pts = (double*)s->stage;
+  uint8_t* d_out = (uint8_t*)(d_pts + n * 3);
+  HIP_TRY(hipMemcpyAsync(d_pts, points3, n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  dim3 grid(blocks_for(n)), block(BLOCK);
+  switch (pick_stack(s->stack_need)) {
+    case 16: hipLaunchKernelGGL((k_points_shadowed<16>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out); break;
+    case 32: hipLaunchKernelGGL((k_points_shadowed<32>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out); break;
+    case 48: hipLaunchKernelGGL((k_points_shadowed<48>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out); break;
+    default: hipLaunchKernelGGL((k_points_shadowed<64>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out); break;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(shadowed, d_out, n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RT_OK;
+}

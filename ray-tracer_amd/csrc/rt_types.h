@@ -1,0 +1,117 @@
+// Device-side scene layout of the MI355X render path (shared by the host
+// builder and the HIP kernels).  Everything a ray touches while traversing is
+// packed into 128-byte records (one MI355X cache line): a BVH node with both
+// child boxes, or one transformed primitive.
+#pragma once
+#include <stdint.h>
+
+namespace rt {
+
+constexpr double FEQ_EPSILON = 0.0001;  // reference src/consts.rs:7
+constexpr int RECURSION_DEPTH = 5;      // reference src/consts.rs:10 (the depth parallel.rs:47 uses)
+constexpr int MAX_GENERATIONS = RECURSION_DEPTH + 1;
+
+// 32-bit traversal reference: kind in the top two bits.
+//   inner node : index in the low 30 bits
+//   tri / quad : run of (count) records, count-1 in bits 27..29, first index in the low 27 bits
+//   gate       : index in the low 30 bits
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
+constexpr uint32_t KIND_INNER = 0, KIND_TRI = 1, KIND_QUAD = 2, KIND_GATE = 3;
+constexpr int MAX_RUN = 8;
+constexpr uint32_t MAX_RUN_FIRST = (1u << 27) - 1;
+constexpr int TRAVERSAL_STACK = 64;  // entries per ray; the builder keeps tree depth below this
+
+inline uint32_t make_ref(uint32_t kind, uint32_t index) { return (kind << 30) | index; }
+inline uint32_t make_run(uint32_t kind, uint32_t first, uint32_t count) {
+  return (kind << 30) | ((count - 1) << 27) | first;
+}
+
+// Binary BVH node holding the world-space boxes of both children (f64).
+struct alignas(128) BvhNode {
+  double lo0[3], hi0[3];
+  double lo1[3], hi1[3];
+  uint32_t c0, c1;
+  uint32_t pad[6];
+};
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be one cache line");
+
+// Triangle as the intersection routine needs it (reference src/shape.rs:1225-1260).
+struct TriIsect {
+  double p1[3], e1[3], e2[3];
+  int32_t leaf;   // depth-first leaf index (tie-break order and shading lookup)
+  int32_t xform;  // index into xforms, or -1 when the ray needs no transform (identity)
+};
+static_assert(sizeof(TriIsect) == 80, "TriIsect layout");
+
+// Sphere / plane / cube / cylinder / cone with its world->object matrix.
+struct alignas(128) QuadPrim {
+  double m[12];  // rows 0..2 of ray_inv
+  double minimum, maximum;
+  int32_t type, closed, leaf, gate;  // gate: innermost group (used for unbounded primitives only)
+};
+static_assert(sizeof(QuadPrim) == 128, "QuadPrim must be one cache line");
+
+// One reference Group: exact bounding-box gate in group space, then its subtree.
+struct alignas(32) Gate {
+  double m[12];  // rows 0..2 of to_local
+  double bmin[3], bmax[3];
+  uint32_t root;  // traversal reference of the subtree (REF_NONE when empty)
+  int32_t parent;
+  uint32_t pad[2];
+};
+static_assert(sizeof(Gate) == 160, "Gate layout");
+
+// Per-leaf shading lookup, indexed by depth-first leaf index.
+struct LeafShade {
+  int32_t type, closed, material, xform;
+  int32_t tri;  // triangle index or -1
+  int32_t pad;
+  double minimum, maximum;
+  double plane_normal[3];
+};
+static_assert(sizeof(LeafShade) == 64, "LeafShade layout");
+
+struct XformDev {
+  double ray_inv[12];
+  double full_inv[12];
+};
+
+struct TriShade {
+  double normal[3];
+  double n1[3], n2[3], n3[3];
+};
+
+struct MaterialDev {
+  double color[3];
+  double ambient, diffuse, specular, shininess;
+  double reflective, refractive_index, transparency;
+  int32_t pattern;
+  int32_t flags;  // bit0: !feq(reflective,0); bit1: !feq(transparency,0); bit2: schlick mix
+};
+
+struct PatternDev {
+  int32_t type, first, second, pad;
+  double inv[12];
+  double a[3], b[3];
+};
+
+struct SceneDev {
+  const BvhNode* nodes;
+  const TriIsect* tris;
+  const QuadPrim* quads;
+  const Gate* gates;
+  const QuadPrim* unbounded;  // tested for every ray (planes, infinite cylinders, very large shapes)
+  const LeafShade* leaves;
+  const XformDev* xforms;
+  const TriShade* tri_shade;
+  const MaterialDev* materials;
+  const PatternDev* patterns;
+  uint32_t root;
+  int32_t n_unbounded;
+  int32_t n_leaves;
+  int32_t pad;
+  double light_intensity[3];
+  double light_position[3];
+};
+
+}  // namespace rt

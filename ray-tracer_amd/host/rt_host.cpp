@@ -1,0 +1,889 @@
+// Host side of the MI355X render path; see rt_host.hpp.  Citations are
+// reference file:line (paths relative to the reference crate).
+#include "rt_host.hpp"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <thread>
+
+namespace rthost {
+
+static const double INF = std::numeric_limits<double>::infinity();
+static inline bool feq(double a, double b) { return std::fabs(a - b) < 0.0001; }  // src/lib.rs:217-219
+
+// ===========================================================================
+// Matrix4D (src/matrix.rs)
+// ===========================================================================
+Mat4 Mat4::identity() {
+  Mat4 r{};
+  r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0;
+  return r;
+}
+
+Mat4 Mat4::operator*(const Mat4& o) const {
+  Mat4 r{};
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      r.m[i * 4 + j] = m[i * 4 + 0] * o.m[0 * 4 + j] + m[i * 4 + 1] * o.m[1 * 4 + j] +
+                       m[i * 4 + 2] * o.m[2 * 4 + j] + m[i * 4 + 3] * o.m[3 * 4 + j];
+  return r;
+}
+
+namespace {
+
+// Determinant of the 3x3 matrix left after deleting one row and one column,
+// expanded along its first row from 2x2 determinants (src/matrix.rs:122-124,
+// 168-210), accumulating from 0.0 in column order.
+double minor4(const double* a, int skip_row, int skip_col) {
+  double s[9];
+  int k = 0;
+  for (int r = 0; r < 4; r++) {
+    if (r == skip_row) continue;
+    for (int c = 0; c < 4; c++) {
+      if (c == skip_col) continue;
+      s[k++] = a[r * 4 + c];
+    }
+  }
+  const int others[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+  double det = 0.0;
+  for (int c = 0; c < 3; c++) {
+    int c0 = others[c][0], c1 = others[c][1];
+    double minor2 = s[3 + c0] * s[6 + c1] - s[3 + c1] * s[6 + c0];
+    double cof = minor2 * ((c % 2 == 0) ? 1.0 : -1.0);
+    det += s[c] * cof;
+  }
+  return det;
+}
+
+double cofactor4(const double* a, int r, int c) {  // src/matrix.rs:531-534
+  return minor4(a, r, c) * (((r + c) % 2 == 0) ? 1.0 : -1.0);
+}
+
+}  // namespace
+
+bool Mat4::inverse(Mat4* out) const {
+  double det = 0.0;
+  for (int c = 0; c < 4; c++) det += m[c] * cofactor4(m, 0, c);  // src/matrix.rs:537-544
+  if (det == 0.0) return false;
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) out->m[c * 4 + r] = cofactor4(m, r, c) / det;  // src/matrix.rs:556-561
+  return true;
+}
+
+Mat4 Mat4::inverse_or_panic(const char* msg) const {
+  Mat4 r;
+  if (!inverse(&r)) throw Panic(msg);
+  return r;
+}
+
+namespace {
+struct Vec4 {
+  double x, y, z, w;
+};
+Vec4 sub(Vec4 a, Vec4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+Vec4 normalize4(Vec4 a) {  // src/tuple.rs:111-135: w takes part; multiply by the reciprocal
+  double mag = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  return {a.x * (1.0 / mag), a.y * (1.0 / mag), a.z * (1.0 / mag), a.w * (1.0 / mag)};
+}
+Vec4 cross3(Vec4 a, Vec4 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x, 0.0};
+}
+Vec4 apply(const Mat4& t, Vec4 p) {  // src/matrix.rs:638-653
+  double b[4];
+  for (int r = 0; r < 4; r++) b[r] = t.m[r * 4] * p.x + t.m[r * 4 + 1] * p.y + t.m[r * 4 + 2] * p.z + t.m[r * 4 + 3] * p.w;
+  return {b[0], b[1], b[2], b[3]};
+}
+}  // namespace
+
+Mat4 view_transform(const double from[3], const double to[3], const double up[4]) {
+  Vec4 f{from[0], from[1], from[2], 1.0}, t{to[0], to[1], to[2], 1.0}, u{up[0], up[1], up[2], up[3]};
+  Vec4 forward = normalize4(sub(t, f));
+  Vec4 left = cross3(forward, normalize4(u));
+  Vec4 true_up = cross3(left, forward);
+  Mat4 o = Mat4::identity();
+  o.m[0] = left.x; o.m[1] = left.y; o.m[2] = left.z;
+  o.m[4] = true_up.x; o.m[5] = true_up.y; o.m[6] = true_up.z;
+  o.m[8] = -forward.x; o.m[9] = -forward.y; o.m[10] = -forward.z;
+  Mat4 tr = Mat4::identity();
+  tr.m[3] = -f.x; tr.m[7] = -f.y; tr.m[11] = -f.z;
+  return o * tr;
+}
+
+// ===========================================================================
+// Camera (src/camera.rs)
+// ===========================================================================
+Camera Camera::make(size_t hsize, size_t vsize, double fov, const Mat4& transform) {
+  Camera c;
+  double half_view = std::tan(fov / 2.0);
+  double aspect = (double)hsize / (double)vsize;
+  if (aspect >= 1.0) {
+    c.half_width = half_view;
+    c.half_height = half_view / aspect;
+  } else {
+    c.half_width = half_view * aspect;
+    c.half_height = half_view;
+  }
+  c.pixel_size = c.half_width * 2.0 / (double)hsize;
+  c.hsize = hsize;
+  c.vsize = vsize;
+  c.field_of_view = fov;
+  c.transform = transform;
+  return c;
+}
+
+rt_camera Camera::describe() const {
+  rt_camera c{};
+  c.hsize = (uint32_t)hsize;
+  c.vsize = (uint32_t)vsize;
+  c.half_width = half_width;
+  c.half_height = half_height;
+  c.pixel_size = pixel_size;
+  Mat4 inv = transform.inverse_or_panic("Camera matrix should have an inverse.");
+  memcpy(c.inv, inv.m, sizeof(c.inv));
+  return c;
+}
+
+// ===========================================================================
+// Scene JSON (src/scene.rs) -- a small JSON reader, then the conversions
+// ===========================================================================
+namespace {
+
+struct Json {
+  enum T { Nul, Boolean, Number, String, Array, Object } t = Nul;
+  double num = 0;
+  bool integral = false;
+  bool flag = false;
+  std::string str;
+  std::vector<Json> items;
+  std::vector<std::string> keys;  // parallel to items for objects
+
+  const Json* field(const std::string& k) const {
+    for (size_t i = keys.size(); i-- > 0;)
+      if (keys[i] == k) return &items[i];
+    return nullptr;
+  }
+};
+
+class JsonReader {
+ public:
+  explicit JsonReader(const std::string& s) : s_(s) {}
+  Json parse() {
+    Json v = value();
+    skip();
+    if (i_ != s_.size()) err("trailing characters");
+    return v;
+  }
+
+ private:
+  const std::string& s_;
+  size_t i_ = 0;
+  [[noreturn]] void err(const std::string& what) const {
+    throw Panic("Failed to parse scene JSON: " + what + " at byte " + std::to_string(i_));
+  }
+  void skip() {
+    while (i_ < s_.size() && strchr(" \t\r\n", s_[i_])) i_++;
+  }
+  bool eat(char c) {
+    skip();
+    if (i_ < s_.size() && s_[i_] == c) {
+      i_++;
+      return true;
+    }
+    return false;
+  }
+  bool literal(const char* w) {
+    size_t n = strlen(w);
+    if (s_.compare(i_, n, w) == 0) {
+      i_ += n;
+      return true;
+    }
+    return false;
+  }
+  std::string text() {
+    std::string out;
+    i_++;
+    for (;;) {
+      if (i_ >= s_.size()) err("unterminated string");
+      char c = s_[i_++];
+      if (c == '"') break;
+      if (c != '\\') {
+        out.push_back(c);
+        continue;
+      }
+      if (i_ >= s_.size()) err("bad escape");
+      char e = s_[i_++];
+      switch (e) {
+        case 'n': out.push_back('\n'); break;
+        case 't': out.push_back('\t'); break;
+        case 'r': out.push_back('\r'); break;
+        case 'b': out.push_back('\b'); break;
+        case 'f': out.push_back('\f'); break;
+        case 'u': {
+          if (i_ + 4 > s_.size()) err("bad unicode escape");
+          unsigned cp = (unsigned)std::stoul(s_.substr(i_, 4), nullptr, 16);
+          i_ += 4;
+          if (cp < 0x80) out.push_back((char)cp);
+          else if (cp < 0x800) {
+            out.push_back((char)(0xC0 | (cp >> 6)));
+            out.push_back((char)(0x80 | (cp & 63)));
+          } else {
+            out.push_back((char)(0xE0 | (cp >> 12)));
+            out.push_back((char)(0x80 | ((cp >> 6) & 63)));
+            out.push_back((char)(0x80 | (cp & 63)));
+          }
+          break;
+        }
+        default: out.push_back(e);  // \" \\ \/
+      }
+    }
+    return out;
+  }
+  Json value() {
+    skip();
+    if (i_ >= s_.size()) err("unexpected end of input");
+    Json v;
+    char c = s_[i_];
+    if (c == '{') {
+      i_++;
+      v.t = Json::Object;
+      if (eat('}')) return v;
+      do {
+        skip();
+        if (i_ >= s_.size() || s_[i_] != '"') err("expected an object key");
+        v.keys.push_back(text());
+        if (!eat(':')) err("expected ':'");
+        v.items.push_back(value());
+      } while (eat(','));
+      if (!eat('}')) err("expected '}'");
+    } else if (c == '[') {
+      i_++;
+      v.t = Json::Array;
+      if (eat(']')) return v;
+      do v.items.push_back(value());
+      while (eat(','));
+      if (!eat(']')) err("expected ']'");
+    } else if (c == '"') {
+      v.t = Json::String;
+      v.str = text();
+    } else if (literal("true")) {
+      v.t = Json::Boolean;
+      v.flag = true;
+    } else if (literal("false")) {
+      v.t = Json::Boolean;
+    } else if (literal("null")) {
+      v.t = Json::Nul;
+    } else {
+      size_t b = i_;
+      while (i_ < s_.size() && (isdigit((unsigned char)s_[i_]) || strchr("+-.eE", s_[i_]))) i_++;
+      if (b == i_) err("unexpected character");
+      std::string lit = s_.substr(b, i_ - b);
+      char* endp = nullptr;
+      v.t = Json::Number;
+      v.num = strtod(lit.c_str(), &endp);  // correctly rounded, as serde_json is on short decimals
+      if (*endp) err("malformed number");
+      v.integral = lit.find_first_of(".eE") == std::string::npos;
+    }
+    return v;
+  }
+};
+
+[[noreturn]] void jerr(const std::string& what) { throw Panic("Failed to parse scene JSON: " + what); }
+const Json& required(const Json& o, const char* k) {
+  if (o.t != Json::Object) jerr("expected an object");
+  const Json* f = o.field(k);
+  if (!f) jerr(std::string("missing field `") + k + "`");
+  return *f;
+}
+const Json* optional(const Json& o, const char* k) {
+  const Json* f = o.field(k);
+  return f && f->t != Json::Nul ? f : nullptr;
+}
+double number(const Json& j) {
+  if (j.t != Json::Number) jerr("expected a number");
+  return j.num;
+}
+size_t unsigned_int(const Json& j) {
+  if (j.t != Json::Number || !j.integral || j.num < 0) jerr("expected an unsigned integer");
+  return (size_t)j.num;
+}
+std::vector<double> numbers(const Json& j) {
+  if (j.t != Json::Array) jerr("expected an array of numbers");
+  std::vector<double> v;
+  for (const Json& e : j.items) v.push_back(number(e));
+  return v;
+}
+// `From<&Vec<f64>>` for Tuple4D / Color: missing trailing entries are zero (src/tuple.rs:62-72)
+void fill(double* dst, int n, const std::vector<double>& v) {
+  for (int i = 0; i < n; i++) dst[i] = i < (int)v.size() ? v[i] : 0.0;
+}
+Mat4 matrix_of(const std::vector<double>& v) {  // src/scene.rs:190-195
+  if (v.size() > 16) throw Panic("index out of bounds: the len is 16 but a transform lists more elements");
+  Mat4 m{};
+  for (size_t i = 0; i < v.size(); i++) m.m[i] = v[i];
+  return m;
+}
+
+Pattern pattern_of(const Json& j) {  // src/scene.rs:275-366
+  const Json& ty = required(j, "ty");
+  if (ty.t != Json::String) jerr("pattern ty must be a string");
+  Pattern p;
+  static const std::pair<const char*, int> names[] = {
+      {"null", RT_PAT_NULL},     {"point", RT_PAT_POINT},     {"identity", RT_PAT_IDENTITY}, {"stripe", RT_PAT_STRIPE},
+      {"ring", RT_PAT_RING},     {"checker", RT_PAT_CHECKER}, {"gradient", RT_PAT_GRADIENT}};
+  bool known = false;
+  for (auto& n : names)
+    if (ty.str == n.first) {
+      p.type = n.second;
+      known = true;
+    }
+  const Json* pri = optional(j, "primary_color");
+  const Json* sec = optional(j, "secondary_color");
+  if (pri) fill(p.a, 3, numbers(*pri));
+  if (sec) fill(p.b, 3, numbers(*sec));
+  if (!known) throw Panic("Unrecognized pattern in scene description JSON.");
+  if (const Json* t = optional(j, "transform")) p.transform = matrix_of(numbers(*t));
+  return p;
+}
+
+Material material_of(const Json& j) {  // src/scene.rs:224-265
+  Material m;
+  fill(m.color, 3, numbers(required(j, "color")));
+  if (const Json* p = optional(j, "pattern")) m.pattern = pattern_of(*p);
+  struct { const char* key; double* dst; } scalars[] = {
+      {"ambient", &m.ambient}, {"diffuse", &m.diffuse}, {"specular", &m.specular}, {"shininess", &m.shininess},
+      {"reflective", &m.reflective}, {"refractive_index", &m.refractive_index}, {"transparency", &m.transparency}};
+  for (auto& s : scalars)
+    if (const Json* v = optional(j, s.key)) *s.dst = number(*v);
+  return m;
+}
+
+Shape leaf_shape(int type, double mn = 0, double mx = 0, int closed = 0) {
+  Shape s;
+  s.type = type;
+  s.minimum = mn;
+  s.maximum = mx;
+  s.closed = closed;
+  return s;
+}
+
+std::string resolve(const std::string& base, const std::string& rel) {
+  if (base.empty() || (!rel.empty() && rel[0] == '/')) return rel;
+  return base + "/" + rel;
+}
+
+Shape shape_of(const Json& j, const std::string& base_dir) {  // src/scene.rs:95-207
+  const Json& tyj = required(j, "ty");
+  if (tyj.t != Json::String) jerr("shape ty must be a string");
+  const std::string& ty = tyj.str;
+  const Json* kids = optional(j, "children");
+  if (kids && kids->t != Json::Array) jerr("children must be an array");
+  Shape s;
+  if (ty == "empty") s = leaf_shape(RT_EMPTY);
+  else if (ty == "sphere") s = leaf_shape(RT_SPHERE);
+  else if (ty == "plane") s = leaf_shape(RT_PLANE);
+  else if (ty == "cube") s = leaf_shape(RT_CUBE);
+  else if (ty == "cylinder") s = leaf_shape(RT_CYLINDER, -1.0 * INF, INF, 0);   // src/shape.rs:245-254
+  else if (ty == "bounded_cylinder") s = leaf_shape(RT_CYLINDER, -1.0, 1.0, 0);
+  else if (ty == "capped_cylinder") s = leaf_shape(RT_CYLINDER, -1.0, 1.0, 1);
+  else if (ty == "bounded_cone") s = leaf_shape(RT_CONE, 0.0, 1.0, 0);
+  else if (ty == "bounded_dn_cone") s = leaf_shape(RT_CONE, -1.0, 1.0, 0);
+  else if (ty == "capped_cone") s = leaf_shape(RT_CONE, 0.0, 1.0, 1);
+  else if (ty == "capped_dn_cone") s = leaf_shape(RT_CONE, -1.0, 1.0, 1);
+  else if (ty == "group") {
+    s.kind = Shape::Group;
+    if (kids)
+      for (const Json& k : kids->items) s.children.push_back(shape_of(k, base_dir));
+  } else if (ty == "union" || ty == "intersection" || ty == "difference") {
+    if (kids) {
+      if (kids->items.size() < 2) throw Panic("CSG union must have at least two operands.");
+      s.kind = Shape::Csg;
+      s.children.push_back(shape_of(kids->items[0], base_dir));
+      s.children.push_back(shape_of(kids->items[1], base_dir));
+    } else {
+      s = leaf_shape(RT_EMPTY);  // src/scene.rs:124,138,152: no children leaves Shape::empty()
+    }
+  } else if (ty == "model") {
+    const Json* path = optional(j, "path");
+    if (!path) throw Panic("Model requires a path in scene description JSON.");
+    if (path->t != Json::String) jerr("path must be a string");
+    std::string full = resolve(base_dir, path->str);
+    std::ifstream f(full, std::ios::binary);
+    if (!f) throw Panic("Failed to open file \"" + full + "\".");
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::map<std::string, Shape> groups = obj_groups_from_text(ss.str(), nullptr);
+    s.kind = Shape::Group;
+    for (auto& kv : groups) s.children.push_back(std::move(kv.second));  // BTreeMap order (src/scene.rs:175)
+  } else {
+    throw Panic("Unrecognized shape type in scene description JSON.");
+  }
+  if (const Json* t = optional(j, "transform")) s.transform = matrix_of(numbers(*t));
+  else s.transform = Mat4::identity();
+  // set_transform inverts at load time (src/shape.rs:597-599)
+  (void)s.transform.inverse_or_panic("Shape transform should have an inverse.");
+  if (const Json* m = optional(j, "material")) s.material = material_of(*m);
+  return s;
+}
+
+// ---- OBJ (src/obj.rs)
+std::vector<std::string> split_on(const std::string& s, char sep) {
+  std::vector<std::string> parts;
+  size_t b = 0;
+  for (size_t i = 0; i <= s.size(); i++)
+    if (i == s.size() || s[i] == sep) {
+      parts.push_back(s.substr(b, i - b));
+      b = i + 1;
+    }
+  return parts;
+}
+bool to_f64(const std::string& s, double* v) {
+  if (s.empty() || isspace((unsigned char)s[0]) || s.find_first_of("xX") != std::string::npos) return false;
+  char* e = nullptr;
+  *v = strtod(s.c_str(), &e);
+  return e != s.c_str() && !*e;
+}
+bool to_index(const std::string& s, size_t* v) {
+  size_t i = (!s.empty() && s[0] == '+') ? 1 : 0;
+  if (i >= s.size()) return false;
+  size_t acc = 0;
+  for (; i < s.size(); i++) {
+    if (!isdigit((unsigned char)s[i])) return false;
+    acc = acc * 10 + (size_t)(s[i] - '0');
+  }
+  *v = acc;
+  return true;
+}
+
+struct Corner {
+  size_t v = 0, n = 0;
+  bool has_n = false;
+};
+
+rt_triangle triangle_record(const double* p1, const double* p2, const double* p3) {  // src/geometry.rs:28-33
+  rt_triangle t{};
+  for (int a = 0; a < 3; a++) {
+    t.p1[a] = p1[a];
+    t.e1[a] = p2[a] - p1[a];
+    t.e2[a] = p3[a] - p1[a];
+  }
+  Vec4 e1{t.e1[0], t.e1[1], t.e1[2], 0.0}, e2{t.e2[0], t.e2[1], t.e2[2], 0.0};
+  Vec4 n = normalize4(cross3(e2, e1));
+  t.normal[0] = n.x; t.normal[1] = n.y; t.normal[2] = n.z;
+  return t;
+}
+
+}  // namespace
+
+std::map<std::string, Shape> obj_groups_from_text(const std::string& text, size_t* ignored_out) {
+  std::map<std::string, Shape> groups;  // std::map iterates keys in byte order like BTreeMap<String, _>
+  auto new_group = [] {
+    Shape g;
+    g.kind = Shape::Group;
+    return g;
+  };
+  groups.emplace("", new_group());  // src/obj.rs:27-28
+  std::vector<std::array<double, 3>> vertices, normals;
+  std::string current;
+  size_t ignored = 0;
+  size_t pos = 0;
+  while (pos < text.size()) {
+    size_t nl = text.find('\n', pos);
+    std::string line = text.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
+    pos = nl == std::string::npos ? text.size() : nl + 1;
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (line.empty()) continue;
+    std::vector<std::string> params = split_on(line, ' ');  // single spaces only (src/obj.rs:96)
+    auto coord = [&](const std::string& s) {
+      double v;
+      if (!to_f64(s, &v)) throw Panic("called `Result::unwrap()` on an `Err` value: ParseFloatError (OBJ line: " + line + ")");
+      return v;
+    };
+    if (params[0] == "v" || params[0] == "vn") {
+      if (params.size() < 4) {
+        ignored++;
+        continue;
+      }
+      std::array<double, 3> p = {coord(params[1]), coord(params[2]), coord(params[3])};
+      (params[0] == "v" ? vertices : normals).push_back(p);
+    } else if (params[0] == "f") {
+      std::vector<Corner> face;
+      bool skip_line = false;
+      for (size_t k = 1; k < params.size() && !skip_line; k++) {
+        Corner c;
+        if (to_index(params[k], &c.v)) {
+          face.push_back(c);
+          continue;
+        }
+        std::vector<std::string> attrs = split_on(params[k], '/');
+        if (attrs.size() > 3) {
+          skip_line = true;
+          break;
+        }
+        if (!to_index(attrs[0], &c.v)) throw Panic("called `Result::unwrap()` on an `Err` value: ParseIntError (OBJ line: " + line + ")");
+        if (attrs.size() < 3) throw Panic("index out of bounds: OBJ face vertex must be `v`, `v/t/n` or `v//n`");
+        size_t unused;
+        (void)to_index(attrs[1], &unused);
+        c.has_n = to_index(attrs[2], &c.n);
+        face.push_back(c);
+      }
+      if (!skip_line)
+        for (const Corner& c : face)
+          if (c.v > vertices.size() || (c.has_n ? c.n : 0) > normals.size()) skip_line = true;  // src/obj.rs:157-161
+      if (skip_line) {
+        ignored++;
+        continue;
+      }
+      if (face.empty()) throw Panic("attempt to subtract with overflow (OBJ face without vertices)");
+      Shape& group = groups.at(current);
+      for (size_t i = 1; i + 1 < face.size(); i++) {  // fan triangulation (src/obj.rs:236-276)
+        const Corner* c[3] = {&face[0], &face[i], &face[i + 1]};
+        for (auto* cc : c)
+          if (cc->v == 0) throw Panic("index out of bounds: OBJ vertex index 0");
+        Shape t;
+        t.tri = triangle_record(vertices[c[0]->v - 1].data(), vertices[c[1]->v - 1].data(), vertices[c[2]->v - 1].data());
+        for (int a = 0; a < 3; a++) {
+          t.p2[a] = vertices[c[1]->v - 1][a];
+          t.p3[a] = vertices[c[2]->v - 1][a];
+        }
+        if (c[0]->has_n && c[1]->has_n && c[2]->has_n) {
+          for (auto* cc : c)
+            if (cc->n == 0) throw Panic("index out of bounds: OBJ normal index 0");
+          t.type = RT_SMOOTH_TRIANGLE;
+          for (int a = 0; a < 3; a++) {
+            t.tri.n1[a] = normals[c[0]->n - 1][a];
+            t.tri.n2[a] = normals[c[1]->n - 1][a];
+            t.tri.n3[a] = normals[c[2]->n - 1][a];
+          }
+        } else {
+          t.type = RT_TRIANGLE;
+        }
+        group.children.push_back(std::move(t));
+      }
+    } else if (line[0] == 'g') {
+      if (params.size() < 2) {
+        ignored++;
+        continue;
+      }
+      if (!groups.count(params[1])) groups.emplace(params[1], new_group());
+      current = params[1];
+    }
+    ignored++;  // every handled line falls through to the counter (src/obj.rs:192-193)
+  }
+  if (ignored_out) *ignored_out = ignored;
+  return groups;
+}
+
+Scene scene_from_json(const std::string& text, const std::string& base_dir) {  // src/scene.rs:25-50
+  Json root = JsonReader(text).parse();
+  size_t width = unsigned_int(required(root, "canvas_width"));
+  size_t height = unsigned_int(required(root, "canvas_height"));
+  double fov = number(required(root, "field_of_view"));
+  double from[4], to[4], up[4];
+  fill(from, 4, numbers(required(root, "camera_from")));
+  fill(to, 4, numbers(required(root, "camera_to")));
+  fill(up, 4, numbers(required(root, "camera_up")));
+  const Json& light = required(root, "light");
+  Scene sc;
+  fill(sc.world.light_source.intensity, 3, numbers(required(light, "intensity")));
+  fill(sc.world.light_source.position, 3, numbers(required(light, "position")));  // w forced to 1 (src/scene.rs:81)
+  const Json& shapes = required(root, "shapes");
+  if (shapes.t != Json::Array) jerr("shapes must be an array");
+  sc.camera = Camera::make(width, height, fov, view_transform(from, to, up));
+  for (const Json& s : shapes.items) sc.world.objects.push_back(shape_of(s, base_dir));
+  return sc;
+}
+
+// ===========================================================================
+// Flattening: Shape tree -> rt_scene_desc arrays
+// ===========================================================================
+namespace {
+
+struct Box {
+  double lo[3], hi[3];
+};
+
+// Bounds::transform (src/geometry.rs:118-150): eight corners through the full
+// 4x4 product, then NaN-ignoring min / max (f64::min / f64::max == fmin / fmax).
+Box transform_box(const Box& b, const Mat4& t) {
+  Box r;
+  for (int a = 0; a < 3; a++) {
+    r.lo[a] = INF;
+    r.hi[a] = -1.0 * INF;
+  }
+  const int order[8][3] = {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {0, 1, 1}, {1, 0, 0}, {1, 0, 1}, {1, 1, 0}, {1, 1, 1}};
+  for (auto& o : order) {
+    Vec4 c = apply(t, Vec4{o[0] ? b.hi[0] : b.lo[0], o[1] ? b.hi[1] : b.lo[1], o[2] ? b.hi[2] : b.lo[2], 1.0});
+    double v[3] = {c.x, c.y, c.z};
+    for (int a = 0; a < 3; a++) {
+      r.lo[a] = std::fmin(r.lo[a], v[a]);
+      r.hi[a] = std::fmax(r.hi[a], v[a]);
+    }
+  }
+  return r;
+}
+
+// Shape::bounds (src/shape.rs:470-544), including its quirks: a child's box is
+// moved by the GROUP's transform, cones and cylinders use (min,min,min)-(max,max,max).
+Box reference_bounds(const Shape& s) {
+  Box b;
+  auto set = [&](double l0, double l1, double l2, double h0, double h1, double h2) {
+    b.lo[0] = l0; b.lo[1] = l1; b.lo[2] = l2;
+    b.hi[0] = h0; b.hi[1] = h1; b.hi[2] = h2;
+  };
+  if (s.kind == Shape::Group) {
+    set(INF, INF, INF, -1.0 * INF, -1.0 * INF, -1.0 * INF);
+    for (const Shape& c : s.children) {
+      Box cb = transform_box(reference_bounds(c), s.transform);
+      for (int a = 0; a < 3; a++) {
+        b.lo[a] = std::fmin(b.lo[a], cb.lo[a]);
+        b.hi[a] = std::fmax(b.hi[a], cb.hi[a]);
+      }
+    }
+    return b;
+  }
+  if (s.kind == Shape::Csg) {
+    set(-1.0 * INF, -1.0 * INF, -1.0 * INF, INF, INF, INF);
+    return b;
+  }
+  switch (s.type) {
+    case RT_EMPTY: set(0, 0, 0, 0, 0, 0); break;
+    case RT_SPHERE:
+    case RT_CUBE: set(-1.0, -1.0, -1.0, 1.0, 1.0, 1.0); break;
+    case RT_CONE:
+    case RT_CYLINDER: set(s.minimum, s.minimum, s.minimum, s.maximum, s.maximum, s.maximum); break;
+    case RT_TRIANGLE:
+    case RT_SMOOTH_TRIANGLE:
+      for (int a = 0; a < 3; a++) {  // the stored corner points themselves (src/shape.rs:485-494)
+        double p1 = s.tri.p1[a], p2 = s.p2[a], p3 = s.p3[a];
+        b.lo[a] = std::fmin(p1, std::fmin(p2, p3));
+        b.hi[a] = std::fmax(p1, std::fmax(p2, p3));
+      }
+      break;
+    default: set(-1.0 * INF, -1.0 * INF, -1.0 * INF, INF, INF, INF);  // plane
+  }
+  return b;
+}
+
+struct Flattener {
+  FlatWorld out;
+
+  int add_pattern(const Pattern& p) {
+    rt_pattern r{};
+    r.type = p.type;
+    r.first = r.second = -1;
+    if (p.type == RT_PAT_BLEND) {
+      if (!p.first || !p.second) throw Panic("blend pattern without operands");
+      r.first = add_pattern(*p.first);
+      r.second = add_pattern(*p.second);
+    }
+    Mat4 inv = p.transform.inverse_or_panic("Pattern transform should be invertible.");  // src/pattern.rs:199
+    memcpy(r.inv, inv.m, sizeof(r.inv));
+    memcpy(r.a, p.a, sizeof(r.a));
+    memcpy(r.b, p.b, sizeof(r.b));
+    out.patterns.push_back(r);
+    return (int)out.patterns.size() - 1;
+  }
+
+  int add_material(const Material& m) {
+    rt_material r{};
+    memcpy(r.color, m.color, sizeof(r.color));
+    r.ambient = m.ambient; r.diffuse = m.diffuse; r.specular = m.specular; r.shininess = m.shininess;
+    r.reflective = m.reflective; r.refractive_index = m.refractive_index; r.transparency = m.transparency;
+    r.pattern = m.pattern ? add_pattern(*m.pattern) : -1;
+    out.materials.push_back(r);
+    return (int)out.materials.size() - 1;
+  }
+
+  // ray_acc: product of the local inverses of the enclosing groups, outermost last applied first;
+  // parent: product of the enclosing groups' transforms (src/shape.rs:681-736), when has_parent.
+  struct Share {  // records reused by the plain triangles of one group (OBJ meshes)
+    int material = -1, xform = -1;
+  };
+
+  void walk(const Shape& s, const Mat4& ray_acc, bool has_parent, const Mat4& parent, int gate, Share* share) {
+    if (s.kind == Shape::Csg)
+      throw std::invalid_argument("CSG shapes (union / intersection / difference) are not supported on the device path");
+    Mat4 local_inv = s.transform.inverse_or_panic("Shape transform should have an inverse.");
+    Mat4 ray_inv = has_parent ? local_inv * ray_acc : local_inv;
+    if (s.kind == Shape::Group) {
+      if (s.children.empty()) return;  // src/shape.rs:1186-1188
+      rt_gate g{};
+      g.parent = gate;
+      memcpy(g.to_local, ray_inv.m, sizeof(g.to_local));
+      Box b = reference_bounds(s);
+      memcpy(g.bmin, b.lo, sizeof(g.bmin));
+      memcpy(g.bmax, b.hi, sizeof(g.bmax));
+      out.gates.push_back(g);
+      int gi = (int)out.gates.size() - 1;
+      Mat4 child_parent = has_parent ? parent * s.transform : s.transform;
+      Share group_share;
+      for (const Shape& c : s.children) walk(c, ray_inv, true, child_parent, gi, &group_share);
+      return;
+    }
+    rt_leaf L{};
+    L.type = s.type;
+    L.closed = s.closed;
+    L.gate = gate;
+    L.minimum = s.minimum;
+    L.maximum = s.maximum;
+    memcpy(L.plane_normal, s.plane_normal, sizeof(L.plane_normal));
+    L.tri = -1;
+    bool is_tri = s.type == RT_TRIANGLE || s.type == RT_SMOOTH_TRIANGLE;
+    bool plain_tri = is_tri && is_default_material(s.material) && is_identity(s.transform);
+    if (plain_tri && share && share->material >= 0) {
+      L.material = share->material;
+      L.xform = share->xform;
+    } else {
+      L.material = add_material(s.material);
+      rt_xform X{};
+      Mat4 fwd = has_parent ? parent * s.transform : s.transform;
+      // full_transform_inverse = (parent * transform)^-1 (src/shape.rs:730-735); a top-level shape
+      // falls back to its own transform_inverse (src/shape.rs:758-761)
+      Mat4 full = has_parent ? fwd.inverse_or_panic("Shape parent transform and transform should be invertible.") : local_inv;
+      memcpy(X.ray_inv, ray_inv.m, sizeof(X.ray_inv));
+      memcpy(X.full_inv, full.m, sizeof(X.full_inv));
+      memcpy(X.fwd, fwd.m, sizeof(X.fwd));
+      out.xforms.push_back(X);
+      L.xform = (int)out.xforms.size() - 1;
+      if (plain_tri && share) {
+        share->material = L.material;
+        share->xform = L.xform;
+      }
+    }
+    if (is_tri) {
+      out.triangles.push_back(s.tri);
+      L.tri = (int)out.triangles.size() - 1;
+    }
+    out.leaves.push_back(L);
+  }
+
+  static bool is_identity(const Mat4& m) {
+    Mat4 i = Mat4::identity();
+    return memcmp(m.m, i.m, sizeof(m.m)) == 0;
+  }
+  static bool is_default_material(const Material& m) {
+    Material d;
+    return !m.pattern && m.color[0] == d.color[0] && m.color[1] == d.color[1] && m.color[2] == d.color[2] &&
+           m.ambient == d.ambient && m.diffuse == d.diffuse && m.specular == d.specular && m.shininess == d.shininess &&
+           m.reflective == d.reflective && m.refractive_index == d.refractive_index && m.transparency == d.transparency;
+  }
+};
+
+}  // namespace
+
+rt_scene_desc FlatWorld::desc() const {
+  rt_scene_desc d{};
+  d.light = light;
+  d.n_leaves = (int32_t)leaves.size();
+  d.n_gates = (int32_t)gates.size();
+  d.n_xforms = (int32_t)xforms.size();
+  d.n_triangles = (int32_t)triangles.size();
+  d.n_materials = (int32_t)materials.size();
+  d.n_patterns = (int32_t)patterns.size();
+  d.leaves = leaves.data();
+  d.gates = gates.data();
+  d.xforms = xforms.data();
+  d.triangles = triangles.data();
+  d.materials = materials.data();
+  d.patterns = patterns.data();
+  return d;
+}
+
+FlatWorld flatten(const World& w) {
+  Flattener f;
+  Mat4 id = Mat4::identity();
+  for (const Shape& s : w.objects) f.walk(s, id, false, id, -1, nullptr);
+  memcpy(f.out.light.intensity, w.light_source.intensity, sizeof(f.out.light.intensity));
+  memcpy(f.out.light.position, w.light_source.position, sizeof(f.out.light.position));
+  return std::move(f.out);
+}
+
+// ===========================================================================
+// Canvas::save (src/canvas.rs:47-94)
+// ===========================================================================
+std::string ppm_encode(size_t width, size_t height, const uint8_t* rgb8) {
+  std::string out;
+  out.reserve(width * height * 12 + 32);
+  out += "P3\n" + std::to_string(width) + " " + std::to_string(height) + "\n255\n";
+  char num[3][4];
+  size_t len[3];
+  size_t col = 1;
+  for (size_t p = 0; p < width * height; p++) {
+    for (int k = 0; k < 3; k++) len[k] = (size_t)snprintf(num[k], sizeof(num[k]), "%u", (unsigned)rgb8[p * 3 + k]);
+    if (col + len[0] > 70) {
+      out += '\n';
+      out.append(num[0], len[0]); out += ' '; out.append(num[1], len[1]); out += ' '; out.append(num[2], len[2]);
+      col = len[0] + len[1] + len[2] + 3;
+    } else if (col + len[0] + len[1] > 70) {
+      out += ' ';
+      out.append(num[0], len[0]); out += '\n'; out.append(num[1], len[1]); out += ' '; out.append(num[2], len[2]);
+      col = len[1] + len[2] + 2;
+    } else if (col + len[0] + len[1] + len[2] > 70) {
+      out += ' ';
+      out.append(num[0], len[0]); out += ' '; out.append(num[1], len[1]); out += '\n'; out.append(num[2], len[2]);
+      col = len[2] + 1;
+    } else {
+      if (col != 1) {
+        out += ' ';
+        col += 1;
+      }
+      out.append(num[0], len[0]); out += ' '; out.append(num[1], len[1]); out += ' '; out.append(num[2], len[2]);
+      col += len[0] + len[1] + len[2] + 2;
+    }
+  }
+  out += '\n';
+  return out;
+}
+
+// ===========================================================================
+// parallel_render (src/parallel.rs:183-204): image tiles over `jobs` GPUs
+// ===========================================================================
+void parallel_render(const World& world, const Camera& camera, size_t jobs, const std::string& out_path) {
+  if (jobs == 0) throw Panic("assertion failed: size > 0");  // src/parallel.rs:94
+  int have = rt_device_count();
+  if (have < 0) throw std::runtime_error(rt_last_error());
+  if ((size_t)have < jobs) throw std::runtime_error("-j asks for " + std::to_string(jobs) + " GPUs, " + std::to_string(have) + " visible");
+  printf("Rendering using %zu threads...\n", jobs);  // the three lines of src/parallel.rs:188,202-203
+  fflush(stdout);
+  FlatWorld flat = flatten(world);
+  rt_scene_desc desc = flat.desc();
+  rt_camera cam = camera.describe();
+  size_t np = camera.hsize * camera.vsize;
+  std::vector<std::vector<uint8_t>> parts(jobs, std::vector<uint8_t>(np * 3));
+  std::vector<std::string> errors(jobs);
+  auto worker = [&](size_t k) {
+    rt_scene* sc = nullptr;
+    if (rt_scene_create(&desc, (int)k, &sc) != RT_OK ||
+        rt_render_host(sc, &cam, (int)k, (int)jobs, 0, parts[k].data(), nullptr, nullptr, nullptr) != RT_OK)
+      errors[k] = rt_last_error();
+    rt_scene_destroy(sc);
+  };
+  std::vector<std::thread> threads;
+  for (size_t k = 1; k < jobs; k++) threads.emplace_back(worker, k);
+  worker(0);
+  for (auto& t : threads) t.join();
+  for (const std::string& e : errors)
+    if (!e.empty()) throw std::runtime_error(e);
+  // framebuffer gather: every GPU wrote only the 32x32 tiles with (tx + ty) % jobs == its index
+  std::vector<uint8_t>& image = parts[0];
+  const size_t T = 32;
+  for (size_t y = 0; y < camera.vsize; y++)
+    for (size_t x = 0; x < camera.hsize; x++) {
+      size_t owner = (x / T + y / T) % jobs;
+      if (owner) memcpy(&image[(y * camera.hsize + x) * 3], &parts[owner][(y * camera.hsize + x) * 3], 3);
+    }
+  std::string ppm = ppm_encode(camera.hsize, camera.vsize, image.data());
+  std::ofstream of(out_path, std::ios::binary);
+  if (!of) throw Panic("could not create output file " + out_path);
+  of.write(ppm.data(), (std::streamsize)ppm.size());
+  printf("...done.\n\n");
+  printf("Saved render to \"%s\".\n", out_path.c_str());
+}
+
+}  // namespace rthost

@@ -1,0 +1,110 @@
+// Host side of the MI355X render path: the part of the reference crate that
+// stays on the CPU (scene JSON, OBJ models, the Shape tree with its cached
+// transforms and group bounds, the PPM writer, parallel_render's driver) and
+// the flattening of a World into the plain-data description of include/rt_amd.h.
+//
+// The reference is Rust and no Rust toolchain is available, so this mirror is
+// C++; names follow the reference (World, Camera, Shape, Material, Pattern,
+// parallel_render) and citations are reference file:line.
+#pragma once
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+
+namespace rthost {
+
+// A reference `panic!` / `expect` surfaces as this exception and, through the C
+// entry points, as a negative status with the same message.
+struct Panic : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+struct Mat4 {
+  double m[16];
+  static Mat4 identity();
+  Mat4 operator*(const Mat4& o) const;          // src/matrix.rs:604-621
+  bool inverse(Mat4* out) const;                // src/matrix.rs:550-565 (cofactors / determinant)
+  Mat4 inverse_or_panic(const char* msg) const;
+};
+Mat4 view_transform(const double from[3], const double to[3], const double up[4]);  // src/matrix.rs:415-434
+
+struct Pattern {
+  int type = RT_PAT_NULL;
+  double a[3] = {1, 1, 1}, b[3] = {0, 0, 0};
+  Mat4 transform = Mat4::identity();
+  std::shared_ptr<Pattern> first, second;  // blend operands
+};
+
+struct Material {  // src/light.rs:96-112 defaults
+  double color[3] = {1, 1, 1};
+  std::optional<Pattern> pattern;
+  double ambient = 0.1, diffuse = 0.9, specular = 0.9, shininess = 200.0;
+  double reflective = 0.0, refractive_index = 1.0, transparency = 0.0;
+};
+
+struct Shape {
+  enum Kind { Leaf, Group, Csg } kind = Leaf;
+  int type = RT_EMPTY;  // rt_leaf_type for leaves
+  int closed = 0;
+  double minimum = 0, maximum = 0;
+  double plane_normal[3] = {0, 1, 0};
+  rt_triangle tri{};
+  double p2[3] = {0, 0, 0}, p3[3] = {0, 0, 0};  // triangle corners as given (tri keeps p1 and the edges)
+  Material material;
+  Mat4 transform = Mat4::identity();
+  std::vector<Shape> children;
+};
+
+struct PointLight {
+  double intensity[3] = {0, 0, 0};
+  double position[3] = {0, 0, 0};
+};
+
+struct World {
+  std::vector<Shape> objects;
+  PointLight light_source;
+};
+
+struct Camera {  // src/camera.rs:13-30
+  size_t hsize = 0, vsize = 0;
+  double half_width = 0, half_height = 0, pixel_size = 0, field_of_view = 0;
+  Mat4 transform = Mat4::identity();
+  static Camera make(size_t hsize, size_t vsize, double fov, const Mat4& transform);  // src/camera.rs:43-69
+  rt_camera describe() const;  // with transform.inverse() (src/camera.rs:87)
+};
+
+struct Scene {
+  World world;
+  Camera camera;
+};
+
+// src/scene.rs:25-366 and src/obj.rs:26-276.  Model paths resolve against
+// base_dir (the reference resolves them against the process directory).
+Scene scene_from_json(const std::string& text, const std::string& base_dir);
+std::map<std::string, Shape> obj_groups_from_text(const std::string& text, size_t* ignored_lines);
+
+// The flattened World: arrays behind an rt_scene_desc.
+struct FlatWorld {
+  std::vector<rt_leaf> leaves;
+  std::vector<rt_gate> gates;
+  std::vector<rt_xform> xforms;
+  std::vector<rt_triangle> triangles;
+  std::vector<rt_material> materials;
+  std::vector<rt_pattern> patterns;
+  rt_light light;
+  rt_scene_desc desc() const;
+};
+FlatWorld flatten(const World& w);
+
+// Canvas::save (src/canvas.rs:47-94) from already quantised bytes.
+std::string ppm_encode(size_t width, size_t height, const uint8_t* rgb8);
+
+// parallel_render (src/parallel.rs:183-204): `jobs` is the number of GPUs.
+void parallel_render(const World& world, const Camera& camera, size_t jobs, const std::string& out_path);
+
+}  // namespace rthost

@@ -1,0 +1,117 @@
+// C entry points over the host side (rt_host.hpp) for language bindings: load a
+// scene description, flatten it, create the device scene, render.  Every call
+// returns 0 or a negative rt_status; rth_last_error() holds the message.
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "rt_host.hpp"
+
+using namespace rthost;
+
+struct rth_scene {
+  Scene scene;
+  FlatWorld flat;
+  rt_scene* dev = nullptr;
+};
+
+static thread_local std::string g_err;
+
+template <class F>
+static int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const Panic& p) {
+    g_err = p.what();
+    return RT_ERR_INVALID;
+  } catch (const std::invalid_argument& e) {
+    g_err = e.what();
+    return RT_ERR_UNSUPPORTED;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return RT_ERR_INVALID;
+  }
+}
+
+extern "C" {
+
+const char* rth_last_error(void) { return g_err.c_str(); }
+
+// device < 0: parse and flatten only (no GPU needed).
+int rth_scene_from_json(const char* text, const char* base_dir, int device, rth_scene** out) {
+  *out = nullptr;
+  return guarded([&]() -> int {
+    std::unique_ptr<rth_scene> h(new rth_scene());
+    h->scene = scene_from_json(text, base_dir ? base_dir : "");
+    h->flat = flatten(h->scene.world);
+    if (device >= 0) {
+      rt_scene_desc d = h->flat.desc();
+      int rc = rt_scene_create(&d, device, &h->dev);
+      if (rc != RT_OK) {
+        g_err = rt_last_error();
+        return rc;
+      }
+    }
+    *out = h.release();
+    return RT_OK;
+  });
+}
+
+void rth_scene_free(rth_scene* h) {
+  if (!h) return;
+  rt_scene_destroy(h->dev);
+  delete h;
+}
+
+rt_scene* rth_scene_device(rth_scene* h) { return h->dev; }
+
+// out[0..7] = width, height, leaves, gates, xforms, triangles, materials, patterns
+void rth_scene_info(rth_scene* h, uint64_t* out) {
+  out[0] = h->scene.camera.hsize;
+  out[1] = h->scene.camera.vsize;
+  out[2] = h->flat.leaves.size();
+  out[3] = h->flat.gates.size();
+  out[4] = h->flat.xforms.size();
+  out[5] = h->flat.triangles.size();
+  out[6] = h->flat.materials.size();
+  out[7] = h->flat.patterns.size();
+}
+
+const rt_scene_desc* rth_scene_desc(rth_scene* h) {
+  static thread_local rt_scene_desc d;
+  d = h->flat.desc();
+  return &d;
+}
+
+int rth_scene_camera(rth_scene* h, rt_camera* out) {
+  return guarded([&]() -> int {
+    *out = h->scene.camera.describe();
+    return RT_OK;
+  });
+}
+
+// Camera::new again with the same view and field of view.
+void rth_scene_set_canvas(rth_scene* h, uint64_t w, uint64_t hh) {
+  h->scene.camera = Camera::make(w, hh, h->scene.camera.field_of_view, h->scene.camera.transform);
+}
+
+void rth_scene_set_camera(rth_scene* h, uint64_t w, uint64_t hh, double fov, const double* from, const double* to,
+                          const double* up4) {
+  h->scene.camera = Camera::make(w, hh, fov, view_transform(from, to, up4));
+}
+
+// parallel_render: jobs GPUs, writes the PPM.
+int rth_parallel_render(rth_scene* h, uint64_t jobs, const char* out_path) {
+  return guarded([&]() -> int {
+    parallel_render(h->scene.world, h->scene.camera, jobs, out_path);
+    return RT_OK;
+  });
+}
+
+uint64_t rth_ppm_encode(uint64_t w, uint64_t hh, const uint8_t* rgb8, char* buf, uint64_t cap) {
+  std::string s = ppm_encode(w, hh, rgb8);
+  if (buf && cap) memcpy(buf, s.data(), s.size() < cap ? s.size() : cap);
+  return s.size();
+}
+
+}  // extern "C"
