@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec and ms/frame on scenes/teapot.json at 1920x1080.
+
+One step = one frame: every rank renders its interleaved 32x32 tiles of the
+image on its own GPU (scene replicated per GPU), then the framebuffer is
+gathered on rank 0 (RCCL gather of the compact tile buffers) and copied to
+pinned host memory.  `python bench.py` runs one GPU; for N > 1 it is launched
+by torch.distributed.run with one rank per GPU.
+
+A ray is one World::intersect query of the reference algorithm (primary,
+shadow, reflection, refraction).  The scene stays resident in HBM; scene load
+and the BVH build are outside the timed region and reported in `setup`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+TILE = 32
+FP64_VALU_PEAK = 78.6e12  # MI355X vector FP64, FLOP/s (datasheet)
+HBM_PEAK = 8.0e12         # bytes/s (datasheet)
+
+# Algorithmic work per traversal event of the closest-hit and shadow kernels
+# (f64 operations / bytes the algorithm needs, not what the caches move).
+FLOPS_NODE, FLOPS_TRI, FLOPS_QUAD, FLOPS_GATE = 2 * 22, 46, 60 + 30, 36 + 30
+BYTES_NODE, BYTES_TRI, BYTES_QUAD, BYTES_GATE = 128, 80, 128, 160
+BYTES_RAY_TRACE = 48 + 4 + 28   # ray in, leaf flag in, hit record out
+BYTES_RAY_SHADOW = 4 + 24 + 48 + 24  # queue index, origin, ambient + lit terms in, colour out
+
+
+def part_pixel_index(width, height, part, n_parts, device):
+    """Linear pixel indices of the tiles that belong to `part` ((tx + ty) % n_parts == part)."""
+    ys, xs = torch.meshgrid(torch.arange(height, device=device), torch.arange(width, device=device), indexing="ij")
+    owner = ((xs // TILE) + (ys // TILE)) % n_parts
+    return (ys * width + xs)[owner == part].reshape(-1)
+
+
+def kernel_work(stats, which):
+    if which == "trace":
+        nv, tt, qt, gt = stats.node_visits, stats.tri_tests, stats.quadric_tests, stats.gate_tests
+        rays = stats.primary + stats.reflect + stats.refract
+        ray_bytes = BYTES_RAY_TRACE
+    else:
+        nv, tt, qt, gt = stats.shadow_node_visits, stats.shadow_tri_tests, stats.shadow_quadric_tests, stats.shadow_gate_tests
+        rays = stats.shadow
+        ray_bytes = BYTES_RAY_SHADOW
+    flops = nv * FLOPS_NODE + tt * FLOPS_TRI + qt * FLOPS_QUAD + gt * FLOPS_GATE
+    nbytes = nv * BYTES_NODE + tt * BYTES_TRI + qt * BYTES_QUAD + gt * BYTES_GATE + rays * ray_bytes
+    return flops, nbytes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "teapot.json"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline renders every n-th pixel of every n-th row")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (
+            args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    pkg = load_package()
+    t_load = time.perf_counter()
+    scene = pkg.Scene.from_file(args.scene, base_dir=ROOT, device=local_rank)
+    scene.set_canvas(args.width, args.height)
+    load_s = time.perf_counter() - t_load
+    info, foot = scene.info(), scene.footprint()
+    W, H = args.width, args.height
+
+    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device=device)
+    host_frame = torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() if rank == 0 else None
+    if world > 1:
+        idx = [part_pixel_index(W, H, p, world, device) for p in range(world)]
+        n_max = max(int(i.numel()) for i in idx)
+        mine = torch.zeros((n_max, 3), dtype=torch.uint8, device=device)
+        gathered = [torch.zeros((n_max, 3), dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+    flat = frame.view(-1, 3)
+
+    def step():
+        st = scene.render_device(rgb8_ptr=frame.data_ptr(), part=rank, n_parts=world)
+        if world > 1:
+            n = idx[rank].numel()
+            mine[:n] = flat[idx[rank]]
+            dist.gather(mine, gathered, dst=0)
+            if rank == 0:
+                for p in range(1, world):
+                    flat[idx[p]] = gathered[p][: idx[p].numel()]
+        if rank == 0:
+            host_frame.copy_(frame)  # framebuffer on the host
+        return st
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    trace_ms = shadow_ms = 0.0
+    trace_n = shadow_n = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+        trace_ms += st.trace_ms
+        shadow_ms += st.shadow_ms
+        trace_n += st.trace_launches
+        shadow_n += st.shadow_launches
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    rays_step = torch.tensor([float(st.rays)], dtype=torch.float64, device=device)
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(rays_step, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    rays_per_frame = float(rays_step.item())
+
+    # ---- roofline of the dominant kernel (this rank's part), from an instrumented extra frame
+    cst = scene.render_device(rgb8_ptr=frame.data_ptr(), part=rank, n_parts=world, counters=True)
+    kernels = {}
+    for which, ms, n in (("trace", trace_ms, trace_n), ("shadow", shadow_ms, shadow_n)):
+        if n == 0:
+            continue
+        flops, nbytes = kernel_work(cst, which)
+        launches = cst.trace_launches if which == "trace" else cst.shadow_launches
+        avg_s = ms / n * 1e-3
+        kernels[which] = {
+            "avg_launch_ms": ms / n,
+            "flops_per_launch": flops / launches,
+            "bytes_per_launch": nbytes / launches,
+            "tflops": flops / launches / avg_s / 1e12,
+            "gbytes_per_s": nbytes / launches / avg_s / 1e9,
+            "frac_fp64_valu": flops / launches / avg_s / FP64_VALU_PEAK,
+            "frac_hbm": nbytes / launches / avg_s / HBM_PEAK,
+        }
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"])
+    dk = kernels[dominant]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dominant, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    if dk["frac_fp64_valu"] >= dk["frac_hbm"]:
+        roofline = {"bound": "fp64_valu", "achieved": dk["tflops"], "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s",
+                    "frac": dk["frac_fp64_valu"], "traffic": traffic}
+    else:
+        roofline = {"bound": "hbm", "achieved": dk["gbytes_per_s"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": dk["frac_hbm"], "traffic": traffic}
+    roofline.update({"kernel": "k_trace" if dominant == "trace" else "k_shadow", "kernels": kernels,
+                     "note": "MFMA unused (no dense contraction); both ceilings (FP64 VALU 78.6 TFLOP/s, HBM 8 TB/s) are in kernels[*]"})
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle as orc  # test infrastructure, used here only as the timed CPU baseline
+
+        cores = min(16, os.cpu_count() or 1)
+        ref = orc.OracleScene.from_file(args.scene, base_dir=ROOT)
+        ref.set_canvas(W, H)
+        s = args.cpu_stride
+        c0 = time.perf_counter()
+        res = ref.render(jobs=cores, xstep=s, ystep=s)
+        cpu_s = time.perf_counter() - c0
+        cpu_rays = sum(res["counts"])
+        cpu_baseline = {"value": cpu_rays / cpu_s, "unit": "rays/s", "cores": cores, "kind": "port",
+                        "sample": "C++ restatement of the reference algorithm (group box gate + linear scan of all %d "
+                                  "triangles per ray), -j %d, every %dth pixel of every %dth row of the same %dx%d frame: "
+                                  "%d rays in %.2f s" % (info["triangles"], cores, s, s, W, H, cpu_rays, cpu_s)}
+
+    out = {
+        "metric": "rays/sec (node) on scenes/teapot.json at 1080p",
+        "value": rays_per_frame * args.steps / elapsed,
+        "unit": "rays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s at %dx%d: generated models/teapot.obj (%d smooth triangles in %d groups) + floor plane, "
+                        "one point light, recursion depth 5" % (os.path.relpath(args.scene, ROOT), W, H, info["triangles"], info["gates"]),
+            "rays_per_frame": rays_per_frame,
+            "parallelism": "interleaved 32x32 tiles over %d GPU(s), scene replicated, framebuffer gather on rank 0" % world,
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu_baseline,
+        "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": foot["build_seconds"], "scene_bytes": foot["scene_bytes"]},
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

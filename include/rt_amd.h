@@ -153,8 +153,10 @@ typedef struct rt_stats {
   double trace_ms;           /* device time of the closest-hit kernels (HIP events) */
   double shadow_ms;          /* device time of the shadow kernels */
   uint64_t trace_launches, shadow_launches;
-  /* traversal work, filled only under RT_FLAG_COUNTERS */
+  /* traversal work of the closest-hit kernels, filled only under RT_FLAG_COUNTERS */
   uint64_t node_visits, tri_tests, quadric_tests, gate_tests, shaded_hits;
+  /* the same for the shadow kernels */
+  uint64_t shadow_node_visits, shadow_tri_tests, shadow_quadric_tests, shadow_gate_tests;
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

@@ -51,6 +51,10 @@ class RtStats(C.Structure):
         ("quadric_tests", C.c_uint64),
         ("gate_tests", C.c_uint64),
         ("shaded_hits", C.c_uint64),
+        ("shadow_node_visits", C.c_uint64),
+        ("shadow_tri_tests", C.c_uint64),
+        ("shadow_quadric_tests", C.c_uint64),
+        ("shadow_gate_tests", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -1002,7 +1002,7 @@ struct rt_scene {
   int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
   GenBuf gens[MAX_GENERATIONS];
   uint32_t* d_counts = nullptr;             // [gen][2]: shadow queue length, next generation length
-  unsigned long long* d_stats = nullptr;    // 8 counters
+  unsigned long long* d_stats = nullptr;    // 16 counters: closest-hit [0..3], shade [4..6], shadow [8..11]
   uint32_t* h_counts = nullptr;             // pinned mirror
   unsigned long long* h_stats = nullptr;
   uint32_t* d_tiles = nullptr;
@@ -1397,9 +1397,9 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   }
 
   HIP_TRY(hipMalloc((void**)&s->d_counts, MAX_GENERATIONS * 2 * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc((void**)&s->d_stats, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc((void**)&s->d_stats, 16 * sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc((void**)&s->h_counts, MAX_GENERATIONS * 2 * sizeof(uint32_t), hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void**)&s->h_stats, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_stats, 16 * sizeof(unsigned long long), hipHostMallocDefault));
   for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
   return RT_OK;
 }
@@ -1471,10 +1471,10 @@ template <bool COUNT>
 void launch_shadow(rt_scene* s, const GenView& g, uint32_t n, const uint32_t* count) {
   dim3 grid(blocks_for(n)), block(BLOCK);
   switch (pick_stack(s->stack_need)) {
-    case 16: hipLaunchKernelGGL((k_shadow<16, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats); break;
-    case 32: hipLaunchKernelGGL((k_shadow<32, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats); break;
-    case 48: hipLaunchKernelGGL((k_shadow<48, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats); break;
-    default: hipLaunchKernelGGL((k_shadow<64, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats); break;
+    case 16: hipLaunchKernelGGL((k_shadow<16, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats + 8); break;
+    case 32: hipLaunchKernelGGL((k_shadow<32, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats + 8); break;
+    case 48: hipLaunchKernelGGL((k_shadow<48, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats + 8); break;
+    default: hipLaunchKernelGGL((k_shadow<64, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats + 8); break;
   }
 }
 
@@ -1483,7 +1483,7 @@ void launch_shadow(rt_scene* s, const GenView& g, uint32_t n, const uint32_t* co
 int run_generations(rt_scene* s, uint32_t n0, int remaining0, uint32_t flags, bool shade, rt_stats* stats) {
   const bool count = (flags & RT_FLAG_COUNTERS) != 0;
   HIP_TRY(hipMemsetAsync(s->d_counts, 0, MAX_GENERATIONS * 2 * sizeof(uint32_t), s->stream));
-  HIP_TRY(hipMemsetAsync(s->d_stats, 0, 8 * sizeof(unsigned long long), s->stream));
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, 16 * sizeof(unsigned long long), s->stream));
   uint32_t n[MAX_GENERATIONS + 1] = {0};
   n[0] = n0;
   int last = 0;
@@ -1523,7 +1523,7 @@ int run_generations(rt_scene* s, uint32_t n0, int remaining0, uint32_t flags, bo
   }
   HIP_TRY(hipGetLastError());
   if (stats) {
-    HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     stats->node_visits = s->h_stats[0];
     stats->tri_tests = s->h_stats[1];
@@ -1533,6 +1533,10 @@ int run_generations(rt_scene* s, uint32_t n0, int remaining0, uint32_t flags, bo
     stats->shadow = s->h_stats[4];
     stats->reflect = s->h_stats[5];
     stats->refract = s->h_stats[6];
+    stats->shadow_node_visits = s->h_stats[8];
+    stats->shadow_tri_tests = s->h_stats[9];
+    stats->shadow_quadric_tests = s->h_stats[10];
+    stats->shadow_gate_tests = s->h_stats[11];
     stats->trace_ms = 0;
     stats->shadow_ms = 0;
     stats->trace_launches = 0;

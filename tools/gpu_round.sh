@@ -1,0 +1,13 @@
+#!/bin/bash
+# One GPU session: smoke, bench, rocprofv3 kernel trace.  Every GPU step runs under its own time limit
+# and the steps are chained, so trouble ends the script.
+set -o pipefail
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout -k 10 200 python -u -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 || { echo "smoke failed"; tail -20 gpurun_out/smoke.log; exit 1; }
+tail -2 gpurun_out/smoke.log
+timeout -k 10 300 python -u bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err || { echo "bench failed"; tail -20 gpurun_out/bench.err; exit 1; }
+cat gpurun_out/bench.json
+rm -rf gpurun_out/prof
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err || { echo "rocprof failed"; tail -20 gpurun_out/prof.err; exit 1; }
+find gpurun_out/prof -name "*kernel_stats*.csv" | head -3
