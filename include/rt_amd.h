@@ -149,13 +149,13 @@ typedef struct rt_scene_desc {
  * (primary src/world.rs:250, shadow :129, reflection :156, refraction :213). */
 typedef struct rt_stats {
   uint64_t primary, shadow, reflect, refract;
-  double render_ms;          /* wall time of the call */
-  double trace_ms;           /* device time of the closest-hit kernels (HIP events) */
-  double shadow_ms;          /* device time of the shadow kernels */
-  uint64_t trace_launches, shadow_launches;
-  /* traversal work of the closest-hit kernels, filled only under RT_FLAG_COUNTERS */
-  uint64_t node_visits, tri_tests, quadric_tests, gate_tests, shaded_hits;
-  /* the same for the shadow kernels */
+  double render_ms;         /* wall time of the call */
+  double kernel_ms;         /* device time of the generation kernels (HIP events on the library's stream) */
+  uint64_t kernel_launches; /* generation kernels launched = ray generations traced */
+  uint64_t generations;
+  /* traversal work, filled only under RT_FLAG_COUNTERS: closest-hit (and refractive-index) queries... */
+  uint64_t node_visits, tri_tests, quadric_tests, gate_tests;
+  /* ...and shadow queries */
   uint64_t shadow_node_visits, shadow_tri_tests, shadow_quadric_tests, shadow_gate_tests;
 } rt_stats;
 

@@ -42,15 +42,13 @@ class RtStats(C.Structure):
         ("reflect", C.c_uint64),
         ("refract", C.c_uint64),
         ("render_ms", C.c_double),
-        ("trace_ms", C.c_double),
-        ("shadow_ms", C.c_double),
-        ("trace_launches", C.c_uint64),
-        ("shadow_launches", C.c_uint64),
+        ("kernel_ms", C.c_double),
+        ("kernel_launches", C.c_uint64),
+        ("generations", C.c_uint64),
         ("node_visits", C.c_uint64),
         ("tri_tests", C.c_uint64),
         ("quadric_tests", C.c_uint64),
         ("gate_tests", C.c_uint64),
-        ("shaded_hits", C.c_uint64),
         ("shadow_node_visits", C.c_uint64),
         ("shadow_tri_tests", C.c_uint64),
         ("shadow_quadric_tests", C.c_uint64),
@@ -73,7 +71,9 @@ def libraries():
     global _libs
     if _libs is not None:
         return _libs
-    paths = [os.path.join(_LIBDIR, n) for n in ("librt_amd.so", "librt_host.so")]
+    # RT_AMD_LIB / RT_HOST_LIB: file names of alternative builds in lib/ (kernel tuning experiments)
+    names = (os.environ.get("RT_AMD_LIB", "librt_amd.so"), os.environ.get("RT_HOST_LIB", "librt_host.so"))
+    paths = [os.path.join(_LIBDIR, n) for n in names]
     for p in paths:
         if not os.path.exists(p):
             raise RtError(-3, "%s is missing: run `make -C %s` (there is no CPU fallback)" % (p, _HERE))

@@ -70,7 +70,6 @@ uint32_t BvhBuilder::build_range(BuildItem* items, size_t n, int depth, double l
     lo[a] = box.lo[a];
     hi[a] = box.hi[a];
   }
-  max_depth = std::max(max_depth, depth);
   if (leaf_ok(items, n)) return make_leaf(items, n);
 
   size_t mid = 0;
@@ -141,19 +140,107 @@ uint32_t BvhBuilder::build_range(BuildItem* items, size_t n, int depth, double l
     });
   }
 
-  uint32_t idx = (uint32_t)nodes.size();
-  nodes.emplace_back();
+  uint32_t idx = (uint32_t)bin_.size();
+  bin_.emplace_back();
   double l0[3], h0[3], l1[3], h1[3];
   uint32_t c0 = build_range(items, mid, depth + 1, l0, h0);
   uint32_t c1 = build_range(items + mid, n - mid, depth + 1, l1, h1);
-  BvhNode& nd = nodes[idx];
+  BinNode& nd = bin_[idx];
   for (int a = 0; a < 3; a++) {
-    nd.lo0[a] = l0[a]; nd.hi0[a] = h0[a];
-    nd.lo1[a] = l1[a]; nd.hi1[a] = h1[a];
+    nd.lo[0][a] = l0[a]; nd.hi[0][a] = h0[a];
+    nd.lo[1][a] = l1[a]; nd.hi[1][a] = h1[a];
   }
-  nd.c0 = c0;
-  nd.c1 = c1;
-  for (uint32_t& p : nd.pad) p = 0;
+  nd.c[0] = c0;
+  nd.c[1] = c1;
+  return make_ref(KIND_INNER, idx);
+}
+
+namespace {
+float round_down(double v) {
+  float f = (float)v;
+  return (double)f > v ? std::nextafterf(f, -INFINITY) : f;
+}
+float round_up(double v) {
+  float f = (float)v;
+  return (double)f < v ? std::nextafterf(f, INFINITY) : f;
+}
+double half_area3(const double* lo, const double* hi) {
+  double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+}  // namespace
+
+// Collapses the binary tree under bin_ref into 4-wide nodes: start from the two children and keep
+// replacing the inner child with the largest box by its own two children until four slots are used.
+//
+// *need receives the number of stack entries a traversal of the subtree can hold at once: a node
+// keeps at most (children - 1) siblings waiting while one child's subtree is walked, a gate hands
+// over to the subtree behind it, a primitive run needs nothing.
+uint32_t BvhBuilder::collapse(uint32_t bin_ref, int* need) {
+  *need = 0;
+  if (bin_ref == REF_NONE) return bin_ref;
+  if ((bin_ref >> 30) == KIND_GATE) {
+    uint32_t g = bin_ref & 0x3FFFFFFFu;
+    *need = g < gate_need.size() ? gate_need[g] : 0;
+    return bin_ref;
+  }
+  if ((bin_ref >> 30) != KIND_INNER) return bin_ref;
+  struct Slot {
+    double lo[3], hi[3];
+    uint32_t ref;
+  };
+  Slot slots[4];
+  int n = 0;
+  auto add = [&](const BinNode& b, int k) {
+    for (int a = 0; a < 3; a++) {
+      slots[n].lo[a] = b.lo[k][a];
+      slots[n].hi[a] = b.hi[k][a];
+    }
+    slots[n].ref = b.c[k];
+    n++;
+  };
+  {
+    const BinNode& b = bin_[bin_ref & 0x3FFFFFFFu];
+    add(b, 0);
+    add(b, 1);
+  }
+  while (n < 4) {
+    int best = -1;
+    double best_area = -1;
+    for (int i = 0; i < n; i++)
+      if ((slots[i].ref >> 30) == KIND_INNER) {
+        double ar = half_area3(slots[i].lo, slots[i].hi);
+        if (ar > best_area) {
+          best_area = ar;
+          best = i;
+        }
+      }
+    if (best < 0) break;
+    const BinNode b = bin_[slots[best].ref & 0x3FFFFFFFu];
+    slots[best] = slots[n - 1];
+    n--;
+    add(b, 0);
+    add(b, 1);
+  }
+  uint32_t idx = (uint32_t)nodes.size();
+  nodes.emplace_back();
+  uint32_t refs[4];
+  int deepest = 0;
+  for (int i = 0; i < n; i++) {
+    int child_need = 0;
+    refs[i] = collapse(slots[i].ref, &child_need);
+    deepest = std::max(deepest, child_need);
+  }
+  *need = (n - 1) + deepest;
+  BvhNode& out = nodes[idx];
+  for (int c = 0; c < 4; c++) {
+    for (int a = 0; a < 3; a++) {
+      out.plane[0][a][c] = c < n ? round_down(slots[c].lo[a]) : INFINITY;
+      out.plane[1][a][c] = c < n ? round_up(slots[c].hi[a]) : -INFINITY;
+    }
+    out.child[c] = c < n ? refs[c] : REF_NONE;
+    out.pad[c] = 0;
+  }
   return make_ref(KIND_INNER, idx);
 }
 
@@ -163,9 +250,12 @@ uint32_t BvhBuilder::build(std::vector<BuildItem>& items, double lo[3], double h
       lo[a] = INF;
       hi[a] = -INF;
     }
+    stack_need = 0;
     return REF_NONE;
   }
-  return build_range(items.data(), items.size(), 1, lo, hi);
+  bin_.clear();
+  uint32_t root = build_range(items.data(), items.size(), 1, lo, hi);
+  return collapse(root, &stack_need);
 }
 
 }  // namespace rt

@@ -12,19 +12,27 @@ struct BuildItem {
   uint32_t index;
 };
 
+struct BinNode {  // binary SAH node, collapsed into 4-wide BvhNodes afterwards
+  double lo[2][3], hi[2][3];
+  uint32_t c[2];
+};
+
 struct BvhBuilder {
   std::vector<BvhNode> nodes;
   std::vector<uint32_t> tri_order;   // source triangle index of every emitted TriIsect slot
   std::vector<uint32_t> quad_order;  // same for QuadPrim slots
-  int max_depth = 0;                 // deepest chain of inner nodes produced by one build() call
+  int stack_need = 0;                // traversal stack entries the last build()'s subtree can need
+  std::vector<int> gate_need;        // the same for the subtree behind each gate (indexed by gate)
 
   // Builds a subtree over items (reordered in place).  Returns its traversal
   // reference and the union box; REF_NONE when items is empty.
   uint32_t build(std::vector<BuildItem>& items, double lo[3], double hi[3]);
 
  private:
+  std::vector<BinNode> bin_;
   uint32_t build_range(BuildItem* items, size_t n, int depth, double lo[3], double hi[3]);
   uint32_t make_leaf(BuildItem* items, size_t n);
+  uint32_t collapse(uint32_t bin_ref, int* need);
 };
 
 }  // namespace rt

@@ -6,17 +6,20 @@
 // ray per hit.  Here the recursion is unrolled into generations of rays held in
 // HBM (struct-of-arrays, one record per ray):
 //
-//   raygen -> [ trace -> shade -> shadow ] per generation -> resolve (bottom-up) -> output
+//   [ generation kernel ] per generation -> resolve (bottom-up) -> output
 //
-// trace   closest hit of every ray against a world-space BVH (plus the
-//         refractive-index query for hits on transparent materials)
-// shade   hit point, normal, Phong terms, pattern lookup; appends the hit to the
-//         shadow queue and the reflection / refraction rays to the next
-//         generation (wave-level ballot + one atomic per wave)
-// shadow  any-hit query towards the light; picks ambient or full lighting
-// resolve walks the generations backwards and combines each ray's surface
-//         colour with its children's colours in the reference's own expression
-//         order, so the f64 result equals the recursive evaluation
+// generation  one ray per lane, start to finish: camera ray or queued ray ->
+//             closest hit against a world-space BVH (plus the refractive-index
+//             query for hits on transparent materials) -> hit point, normal,
+//             Phong terms, pattern lookup -> reflection / refraction rays
+//             appended to the next generation's queue (wave-level ballot +
+//             prefix, one atomic per wave) -> shadow query towards the light
+//             -> surface colour.  Ray, hit and lighting terms never leave
+//             registers; a scene without reflective or transparent materials
+//             finishes every pixel in this one kernel.
+// resolve     walks the generations backwards and combines each ray's surface
+//             colour with its children's colours in the reference's own
+//             expression order, so the f64 result equals the recursive evaluation
 //
 // All arithmetic is f64 with the reference's operation order; build with
 // -ffp-contract=off (Rust never fuses a multiply with an add).
@@ -26,6 +29,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -262,8 +266,8 @@ struct ClosestQuery {
     best_leaf = 0x7FFFFFFF;
     u = v = 0.0;
   }
-  DEV double lo() const { return 0.0; }
-  DEV double hi() const { return best_t; }
+  DEV float lo_f() const { return 0.0f; }
+  DEV float hi_f() const { return __double2float_ru(best_t); }
   DEV bool done() const { return false; }
   DEV void offer(double t, int leaf, double uu, double vv) {
     if (t >= 0.0 && isfinite(t) && (t < best_t || (t == best_t && leaf < best_leaf))) {
@@ -283,8 +287,8 @@ struct ClosestQuery {
 struct ShadowQuery {
   double distance;
   bool found;
-  DEV double lo() const { return 0.0; }
-  DEV double hi() const { return distance; }
+  DEV float lo_f() const { return 0.0f; }
+  DEV float hi_f() const { return __double2float_ru(distance); }
   DEV bool done() const { return found; }
   DEV void leaf_ts(int, int n, const double* t) {
     for (int i = 0; i < n; i++)
@@ -312,8 +316,8 @@ struct ContainerQuery {
     other_key = -INFINITY;
     other_leaf = -1;
   }
-  DEV double lo() const { return -INFINITY; }
-  DEV double hi() const { return 0.0; }
+  DEV float lo_f() const { return -INFINITY; }
+  DEV float hi_f() const { return 0.0f; }
   DEV bool done() const { return false; }
   DEV void container(int leaf, int count, double key) {
     if (!(count & 1)) return;
@@ -345,6 +349,7 @@ struct ContainerQuery {
 // ---------------------------------------------------------------------------
 // Per-lane stack in LDS: entry e of thread t lives at stack[e * BLOCK + t], so
 // the 64 lanes of a wave hit 64 consecutive banks.
+#ifndef RT_PRIVATE_STACK
 template <int STACK, int BLOCK>
 struct LdsStack {
   uint32_t* base;
@@ -357,17 +362,70 @@ struct LdsStack {
     if (sp < STACK) base[(sp++) * BLOCK] = r;
   }
   DEV uint32_t pop() { return base[(--sp) * BLOCK]; }
+  DEV uint32_t pop_or_none() { return sp > 0 ? base[(--sp) * BLOCK] : REF_NONE; }
   DEV bool empty() const { return sp == 0; }
   DEV void clear() { sp = 0; }
 };
+#define RT_STACK_LDS(n) (n)
+#else
+// Experiment: per-lane stack in private (scratch) memory instead of LDS.
+template <int STACK, int BLOCK>
+struct LdsStack {
+  uint32_t slot[STACK];
+  int sp;
+  DEV void init(uint32_t*) { sp = 0; }
+  DEV void push(uint32_t r) {
+    if (sp < STACK) slot[sp++] = r;
+  }
+  DEV uint32_t pop() { return slot[--sp]; }
+  DEV uint32_t pop_or_none() { return sp > 0 ? slot[--sp] : REF_NONE; }
+  DEV bool empty() const { return sp == 0; }
+  DEV void clear() { sp = 0; }
+};
+#define RT_STACK_LDS(n) 1
+#endif
 
-DEV void slab(const double* lo, const double* hi, const V3& o, const V3& inv, double& tn, double& tf) {
-  double tx0 = (lo[0] - o.x) * inv.x, tx1 = (hi[0] - o.x) * inv.x;
-  double ty0 = (lo[1] - o.y) * inv.y, ty1 = (hi[1] - o.y) * inv.y;
-  double tz0 = (lo[2] - o.z) * inv.z, tz1 = (hi[2] - o.z) * inv.z;
-  // fmin/fmax drop a NaN operand (0 * inf when the origin lies on a slab plane of a parallel ray)
-  tn = fmax(fmax(fmin(tx0, tx1), fmin(ty0, ty1)), fmin(tz0, tz1));
-  tf = fmin(fmin(fmax(tx0, tx1), fmax(ty0, ty1)), fmax(tz0, tz1));
+// What a ray needs for the f32 box tests: t(plane) = plane * inv - origin * inv per axis, the near
+// plane of an axis being the lower one when inv >= 0.  The f32 evaluation of that expression is off
+// by at most 2^-23 * (|origin * inv| + |t|) (rounding of inv, of origin * inv and of the fused
+// multiply-add), so the near value is lowered and the far value raised by 2^-22 of both terms: the
+// interval only ever grows, and a box test can pass wrongly but never fail wrongly.
+struct RayBox {
+  float inv[3];
+  float c_near[3], c_far[3];   // origin * inv plus / minus its error bound
+  uint32_t off_near[3], off_far[3];  // byte offsets of the near / far planes of each axis in a BvhNode
+  bool tiny;                   // some |direction| component is below FEQ_EPSILON
+};
+constexpr float BOX_REL = 2.4e-7f;  // 2^-22
+
+DEV RayBox make_raybox(const Ray& r) {
+  RayBox b;
+  const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+  b.tiny = false;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    double dir = d[a];
+    if (fabs(dir) < FEQ_EPSILON) b.tiny = true;
+    if (!(fabs(dir) >= 1e-20)) dir = copysign(1e-20, dir);  // parallel: a huge finite slope, no inf * 0
+    double inv = 1.0 / dir;
+    double oinv = o[a] * inv;
+    double err = fabs(oinv) * 2.4e-7 + 1e-30;
+    b.inv[a] = (float)inv;
+    b.c_near[a] = __double2float_ru(oinv + err);
+    b.c_far[a] = __double2float_rd(oinv - err);
+    bool neg = inv < 0.0;
+    b.off_near[a] = (neg ? 48u : 0u) + 16u * a;
+    b.off_far[a] = (neg ? 0u : 48u) + 16u * a;
+  }
+  return b;
+}
+
+struct F4 {
+  float v[4];
+};
+DEV F4 load_f4(const char* p) {
+  float4 q = *reinterpret_cast<const float4*>(p);
+  return F4{{q.x, q.y, q.z, q.w}};
 }
 
 template <class Query>
@@ -382,6 +440,10 @@ DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& 
   if (n) Q.leaf_ts(q.leaf, n, t);
 }
 
+// World::intersect (src/world.rs:107-117) over the acceleration structure: first the primitives
+// without a finite box, then the 4-wide BVH.  While-while traversal: every lane first descends
+// inner nodes (the nearest hit child stays in a register, the others go on the LDS stack), and
+// only when all lanes of the wave have reached a primitive run or a gate is that work done.
 template <class Query, class Stack, bool COUNT>
 DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counters& cnt) {
   for (int i = 0; i < S.n_unbounded; i++) {
@@ -389,37 +451,61 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     test_quad(S, S.unbounded[i], ray, Q, true);
   }
   if (S.root == REF_NONE || Q.done()) return;
-  const V3 inv = v3(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+  const RayBox rb = make_raybox(ray);
+  const float qlo = Q.lo_f();
+  float qhi = Q.hi_f();
   st.clear();
-  st.push(S.root);
-  while (!st.empty()) {
-    uint32_t ref = st.pop();
-    uint32_t kind = ref >> 30;
-    if (kind == KIND_INNER) {
-      const BvhNode& nd = S.nodes[ref & 0x3FFFFFFFu];
+  uint32_t cur = S.root;
+  while (cur != REF_NONE) {
+    while ((cur >> 30) == KIND_INNER) {
+      const char* nd = reinterpret_cast<const char*>(S.nodes + (cur & 0x3FFFFFFFu));
       if (COUNT) cnt.node_visits++;
-      double tn0, tf0, tn1, tf1;
-      slab(nd.lo0, nd.hi0, ray.o, inv, tn0, tf0);
-      slab(nd.lo1, nd.hi1, ray.o, inv, tn1, tf1);
-      const double lo = Q.lo(), hi = Q.hi();
-      bool h0 = fmax(tn0, lo) <= fmin(tf0, hi);
-      bool h1 = fmax(tn1, lo) <= fmin(tf1, hi);
-      uint32_t c0 = nd.c0, c1 = nd.c1;
-      if (h0 && h1) {
-        if (tn1 < tn0) {  // nearer child on top
-          st.push(c0);
-          st.push(c1);
-        } else {
-          st.push(c1);
-          st.push(c0);
-        }
-      } else if (h0) {
-        st.push(c0);
-      } else if (h1) {
-        st.push(c1);
+      F4 nx = load_f4(nd + rb.off_near[0]), ny = load_f4(nd + rb.off_near[1]), nz = load_f4(nd + rb.off_near[2]);
+      F4 fx = load_f4(nd + rb.off_far[0]), fy = load_f4(nd + rb.off_far[1]), fz = load_f4(nd + rb.off_far[2]);
+      uint4 ch = *reinterpret_cast<const uint4*>(nd + 96);
+      uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
+      float tn[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        float tnear = fmaxf(fmaxf(fmaf(nx.v[k], rb.inv[0], -rb.c_near[0]), fmaf(ny.v[k], rb.inv[1], -rb.c_near[1])),
+                            fmaf(nz.v[k], rb.inv[2], -rb.c_near[2]));
+        float tfar = fminf(fminf(fmaf(fx.v[k], rb.inv[0], -rb.c_far[0]), fmaf(fy.v[k], rb.inv[1], -rb.c_far[1])),
+                           fmaf(fz.v[k], rb.inv[2], -rb.c_far[2]));
+        tnear = fmaf(-fabsf(tnear), BOX_REL, tnear);
+        tfar = fmaf(fabsf(tfar), BOX_REL, tfar);
+        bool hit = fmaxf(tnear, qlo) <= fminf(tfar, qhi);
+        tn[k] = hit ? tnear : INFINITY;
+        if (!hit) c[k] = REF_NONE;
       }
-    } else if (kind == KIND_TRI) {
-      uint32_t first = ref & MAX_RUN_FIRST, count = ((ref >> 27) & 7u) + 1u;
+      // order the four (distance, child) pairs, nearest first; misses carry +inf and REF_NONE
+#define RT_CSWAP(i, j)                        \
+  if (tn[j] < tn[i]) {                        \
+    float tt = tn[i]; tn[i] = tn[j]; tn[j] = tt; \
+    uint32_t cc = c[i]; c[i] = c[j]; c[j] = cc; \
+  }
+      RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+      if (c[3] != REF_NONE) st.push(c[3]);
+      if (c[2] != REF_NONE) st.push(c[2]);
+      if (c[1] != REF_NONE) st.push(c[1]);
+      cur = c[0] != REF_NONE ? c[0] : st.pop_or_none();
+    }
+    if (cur == REF_NONE) break;
+    const uint32_t kind = cur >> 30;
+    if (kind == KIND_GATE) {
+      const Gate& g = S.gates[cur & 0x3FFFFFFFu];
+      bool pass;
+      if (g.skippable && !rb.tiny) {
+        pass = true;
+      } else {
+        if (COUNT) cnt.gate_tests++;
+        pass = gate_passes(g, ray);
+      }
+      cur = pass ? g.root : st.pop_or_none();
+      continue;
+    }
+    const uint32_t first = cur & MAX_RUN_FIRST, count = ((cur >> 27) & 7u) + 1u;
+    if (kind == KIND_TRI) {
       for (uint32_t i = 0; i < count; i++) {
         const TriIsect& tr = S.tris[first + i];
         if (COUNT) cnt.tri_tests++;
@@ -433,19 +519,15 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
         }
         if (hit) Q.leaf_tri(tr.leaf, t, u, v);
       }
-      if (Q.done()) return;
-    } else if (kind == KIND_QUAD) {
-      uint32_t first = ref & MAX_RUN_FIRST, count = ((ref >> 27) & 7u) + 1u;
+    } else {
       for (uint32_t i = 0; i < count; i++) {
         if (COUNT) cnt.quad_tests++;
         test_quad(S, S.quads[first + i], ray, Q, false);
       }
-      if (Q.done()) return;
-    } else {
-      const Gate& g = S.gates[ref & 0x3FFFFFFFu];
-      if (COUNT) cnt.gate_tests++;
-      if (g.root != REF_NONE && gate_passes(g, ray)) st.push(g.root);
     }
+    if (Q.done()) return;
+    qhi = Q.hi_f();
+    cur = st.pop_or_none();
   }
 }
 
@@ -453,17 +535,13 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
 // ray records: one generation = struct of arrays in HBM
 // ---------------------------------------------------------------------------
 struct GenView {
-  double *ox, *oy, *oz, *dx, *dy, *dz;          // ray
-  double *t, *u, *v, *n1, *n2;                  // hit
-  int32_t* leaf;                                // hit leaf or -1
-  double *px, *py, *pz;                         // over_point (shadow ray origin)
-  double *ar, *ag, *ab;                         // ambient term
-  double *lr, *lg, *lb;                         // ambient + diffuse + specular
-  double *cr, *cg, *cb;                         // surface colour, then the ray's final colour
+  double *ox, *oy, *oz, *dx, *dy, *dz;              // ray (generations >= 1 and caller-supplied rays)
+  double *cr, *cg, *cb;                             // surface colour, then the ray's final colour
   double *reflective, *transparency, *reflectance;  // mix factors of this hit
-  uint32_t *child_reflect, *child_refract;      // indices into the next generation or REF_NONE
-  uint32_t* flags;                              // bit0: hit, bit1: Schlick mix
-  uint32_t* shadow_queue;                       // compacted indices of rays that hit something
+  double* t;                                        // hit distance
+  uint32_t *child_reflect, *child_refract;          // indices into the next generation or REF_NONE
+  uint32_t* flags;                                  // bit0: hit, bit1: Schlick mix
+  int32_t* leaf;                                    // hit leaf or -1
 };
 
 DEV Ray load_ray(const GenView& g, uint32_t i) {
@@ -476,9 +554,26 @@ struct CameraDev {
   double inv[12];
 };
 
-constexpr int TILE = 32;         // multi-GPU partition granule, pixels per side
+struct ImageOut {
+  uint8_t* rgb8;
+  double* rgb64;
+  int32_t* hit_leaf;
+};
+
+constexpr int TILE = 32;  // multi-GPU partition granule, pixels per side
 constexpr int TILE_PIXELS = TILE * TILE;
-constexpr int BLOCK = 256;
+#ifndef RT_BLOCK
+#define RT_BLOCK 256
+#endif
+constexpr int BLOCK = RT_BLOCK;  // threads per workgroup of every kernel
+
+// Device statistics block (unsigned long long): [0..3] closest-hit traversal work,
+// [4..7] shadow traversal work, then three ray counters spread over 64 slots each
+// (shaded hits = shadow rays, reflection rays, refraction rays) so that the per-wave
+// adds do not all land on one address.
+constexpr int STAT_SLOTS = 64;
+constexpr int STAT_RAYS = 8;
+constexpr int STAT_WORDS = STAT_RAYS + 3 * STAT_SLOTS;
 
 // Ray index -> pixel: tile k of this part, then 8x8 pixel blocks per wave so the
 // 64 rays of a wave stay close in screen space.
@@ -504,21 +599,6 @@ DEV Ray camera_ray(const CameraDev& cam, uint32_t px, uint32_t py) {
   return Ray{origin, direction};
 }
 
-__global__ void __launch_bounds__(BLOCK) k_raygen(GenView g, uint32_t n, CameraDev cam, const uint32_t* tiles,
-                                                  uint32_t tiles_x) {
-  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  uint32_t x, y;
-  if (!ray_pixel(tiles, tiles_x, cam, i, x, y)) {
-    g.leaf[i] = -2;  // outside the image: never traced
-    return;
-  }
-  Ray r = camera_ray(cam, x, y);
-  g.ox[i] = r.o.x; g.oy[i] = r.o.y; g.oz[i] = r.o.z;
-  g.dx[i] = r.d.x; g.dy[i] = r.d.y; g.dz[i] = r.d.z;
-  g.leaf[i] = -1;
-}
-
 // Rays supplied by the caller (rt_color_at and friends): Ray4D::new keeps the
 // three components as given.
 __global__ void __launch_bounds__(BLOCK) k_load_rays(GenView g, uint32_t n, const double* rays6) {
@@ -527,7 +607,6 @@ __global__ void __launch_bounds__(BLOCK) k_load_rays(GenView g, uint32_t n, cons
   const double* r = rays6 + (size_t)i * 6;
   g.ox[i] = r[0]; g.oy[i] = r[1]; g.oz[i] = r[2];
   g.dx[i] = r[3]; g.dy[i] = r[4]; g.dz[i] = r[5];
-  g.leaf[i] = -1;
 }
 
 DEV void flush_counters(const Counters& c, unsigned long long* out) {
@@ -538,50 +617,6 @@ DEV void flush_counters(const Counters& c, unsigned long long* out) {
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(&out[k], s);
   }
-}
-
-template <int STACK, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_trace(SceneDev S, GenView g, uint32_t n, unsigned long long* counters) {
-  __shared__ uint32_t lds[STACK * BLOCK];
-  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  Counters cnt = {0, 0, 0, 0};
-  if (i < n && g.leaf[i] != -2) {
-    LdsStack<STACK, BLOCK> st;
-    st.init(lds);
-    Ray ray = load_ray(g, i);
-    ClosestQuery Q;
-    Q.init();
-    traverse<ClosestQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, Q, st, cnt);
-    if (Q.best_leaf == 0x7FFFFFFF) {
-      g.leaf[i] = -1;
-    } else {
-      g.leaf[i] = Q.best_leaf;
-      g.t[i] = Q.best_t;
-      g.u[i] = Q.u;
-      g.v[i] = Q.v;
-      const MaterialDev& m = S.materials[S.leaves[Q.best_leaf].material];
-      if (m.flags & 8) {  // n1 / n2 are consumed: refraction or Schlick
-        ContainerQuery C;
-        C.init(Q.best_leaf);
-        traverse<ContainerQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, C, st, cnt);
-        double ri_hit = m.refractive_index;
-        double ri_other = C.other_leaf >= 0 ? S.materials[S.leaves[C.other_leaf].material].refractive_index : 1.0;
-        double n1, n2;
-        if (C.hit_inside) {
-          bool hit_last = C.other_leaf < 0 || C.hit_key > C.other_key ||
-                          (C.hit_key == C.other_key && C.hit_leaf > C.other_leaf);
-          n1 = hit_last ? ri_hit : ri_other;
-          n2 = ri_other;
-        } else {
-          n1 = ri_other;
-          n2 = ri_hit;
-        }
-        g.n1[i] = n1;
-        g.n2[i] = n2;
-      }
-    }
-  }
-  if (COUNT) flush_counters(cnt, counters);
 }
 
 // ---------------------------------------------------------------------------
@@ -677,44 +712,84 @@ DEV uint32_t wave_append(uint32_t* counter, bool mine) {
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// IntersectionComputation::new (src/intersect.rs:152-184), lighting
-// (src/light.rs:125-174) up to the shadow flag, reflected_color / refracted_color
-// ray set-up (src/world.rs:142-215) and Schlick (src/intersect.rs:240-260).
-__global__ void __launch_bounds__(BLOCK)
-    k_shade(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_capacity, int remaining,
-            uint32_t* shadow_count, uint32_t* next_count, unsigned long long* stats) {
-  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  bool active = i < n;
-  int leaf = active ? g.leaf[i] : -1;
-  bool hit = leaf >= 0;
-  bool want_reflect = false, want_refract = false;
-  Ray reflect_ray, refract_ray;
-  if (active) {
-    g.child_reflect[i] = REF_NONE;
-    g.child_refract[i] = REF_NONE;
-    g.flags[i] = hit ? 1u : 0u;
-    if (!hit) {  // World::color_at: None => black
-      g.cr[i] = 0.0; g.cg[i] = 0.0; g.cb[i] = 0.0;
-    }
+// Canvas::save quantisation (src/canvas.rs:60-62): ceil(clamp(c * 255, 0, 255)); NaN -> 0
+DEV uint8_t quantise(double c) {
+  double v = c * 255.0;
+  if (v < 0.0) v = 0.0;
+  else if (v > 255.0) v = 255.0;
+  v = ceil(v);
+  return (v == v) ? (uint8_t)v : (uint8_t)0;
+}
+
+DEV void write_pixel(const ImageOut& img, size_t p, double r, double g, double b, int leaf) {
+  if (img.rgb64) {
+    img.rgb64[p * 3 + 0] = r; img.rgb64[p * 3 + 1] = g; img.rgb64[p * 3 + 2] = b;
   }
+  if (img.rgb8) {
+    img.rgb8[p * 3 + 0] = quantise(r); img.rgb8[p * 3 + 1] = quantise(g); img.rgb8[p * 3 + 2] = quantise(b);
+  }
+  if (img.hit_leaf) img.hit_leaf[p] = leaf;
+}
+
+// One generation of rays, start to finish, one ray per lane:
+//   ray (camera or queue) -> closest hit (World::intersect + Intersections::hit)
+//   -> IntersectionComputation::new (src/intersect.rs:152-184) -> lighting terms
+//   (src/light.rs:125-174) -> reflection / refraction rays appended to the next
+//   generation (src/world.rs:142-215) -> shadow query (src/world.rs:123-137)
+//   -> surface colour.
+// MODE 0: camera rays of a scene that never spawns rays: the pixel is final, written straight
+//         to the image.  MODE 1: camera rays with ray records.  MODE 2: rays read from g.
+template <int STACK, bool COUNT, int MODE>
+__global__ void __launch_bounds__(BLOCK)
+    k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_capacity, int remaining,
+                 uint32_t* next_count, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
+                 uint32_t tiles_x, ImageOut img) {
+  __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
+  LdsStack<STACK, BLOCK> st;
+  st.init(lds);
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  bool active = i < n;
+  size_t pixel = 0;
+  Ray ray{v3(0, 0, 0), v3(0, 0, 1)};
+  if (MODE != 2) {
+    uint32_t x = 0, y = 0;
+    active = active && ray_pixel(tiles, tiles_x, cam, i, x, y);
+    if (active) {
+      ray = camera_ray(cam, x, y);
+      pixel = (size_t)y * cam.hsize + x;
+    }
+  } else if (active) {
+    ray = load_ray(g, i);
+  }
+
+  Counters ct = {0, 0, 0, 0}, cs = {0, 0, 0, 0};
+  ClosestQuery Q;
+  Q.init();
+  if (active) traverse<ClosestQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, Q, st, ct);
+  const bool hit = active && Q.best_leaf != 0x7FFFFFFF;
+  const int leaf = hit ? Q.best_leaf : -1;
+
+  bool want_reflect = false, want_refract = false;
+  Ray reflect_ray{v3(0, 0, 0), v3(0, 0, 0)}, refract_ray{v3(0, 0, 0), v3(0, 0, 0)};
+  V3 over_point = v3(0, 0, 0);
+  double ar = 0, ag = 0, ab = 0, lr = 0, lg = 0, lb = 0;
+  double k_reflective = 0, k_transparency = 0, reflectance = 0;
+  uint32_t flags = hit ? 1u : 0u;
   if (hit) {
     const LeafShade L = S.leaves[leaf];
     const MaterialDev m = S.materials[L.material];
     const XformDev& X = S.xforms[L.xform];
-    Ray ray = load_ray(g, i);
-    double t = g.t[i];
+    const double t = Q.best_t;
     V3 point = ray.o + (ray.d * t);  // Ray4D::position
     V3 eyev = -ray.d;
     // normal_at (src/shape.rs:1478-1484)
     V3 local_point = mul_point(X.full_inv, point);
-    V3 ln = local_normal(S, L, local_point, g.u[i], g.v[i]);
+    V3 ln = local_normal(S, L, local_point, Q.u, Q.v);
     const double* fi = X.full_inv;  // transposition() * normal, w dropped, normalize
     V3 normalv = normalize(v3(fi[0] * ln.x + fi[4] * ln.y + fi[8] * ln.z, fi[1] * ln.x + fi[5] * ln.y + fi[9] * ln.z,
                               fi[2] * ln.x + fi[6] * ln.y + fi[10] * ln.z));
     if (dot(normalv, eyev) < 0.0) normalv = -normalv;
-    V3 over_point = point + normalv * FEQ_EPSILON;
-    V3 under_point = point - normalv * FEQ_EPSILON;
-    V3 reflectv = reflect(ray.d, normalv);
+    over_point = point + normalv * FEQ_EPSILON;
 
     // lighting(): evaluated at over_point, pattern included (src/world.rs:223-227)
     double cr, cg, cb;
@@ -728,7 +803,7 @@ __global__ void __launch_bounds__(BLOCK)
     double er = cr * S.light_intensity[0], eg = cg * S.light_intensity[1], eb = cb * S.light_intensity[2];
     V3 lightpos = v3(S.light_position[0], S.light_position[1], S.light_position[2]);
     V3 lightv = normalize(lightpos - over_point);
-    double ar = er * m.ambient, ag = eg * m.ambient, ab = eb * m.ambient;
+    ar = er * m.ambient; ag = eg * m.ambient; ab = eb * m.ambient;
     double dr = 0.0, dg = 0.0, db = 0.0, sr = 0.0, sg = 0.0, sb = 0.0;
     double light_dot_normal = dot(lightv, normalv);
     if (!(light_dot_normal < 0.0)) {
@@ -744,110 +819,130 @@ __global__ void __launch_bounds__(BLOCK)
         sb = S.light_intensity[2] * m.specular * factor;
       }
     }
-    g.px[i] = over_point.x; g.py[i] = over_point.y; g.pz[i] = over_point.z;
-    g.ar[i] = ar; g.ag[i] = ag; g.ab[i] = ab;
-    g.lr[i] = ar + dr + sr; g.lg[i] = ag + dg + sg; g.lb[i] = ab + db + sb;
-    g.reflective[i] = m.reflective;
-    g.transparency[i] = m.transparency;
+    lr = ar + dr + sr; lg = ag + dg + sg; lb = ab + db + sb;
 
-    // reflected_color (src/world.rs:142-159)
-    if (remaining != 0 && (m.flags & 1)) {
-      want_reflect = true;
-      reflect_ray = Ray{over_point, reflectv};
-    }
-    double n1 = 1.0, n2 = 1.0;
-    if (m.flags & 8) {
-      n1 = g.n1[i];
-      n2 = g.n2[i];
-    }
-    // refracted_color (src/world.rs:181-215)
-    if (remaining != 0 && (m.flags & 2)) {
-      double n_ratio = n1 / n2;
-      double cos_i = dot(eyev, normalv);
-      double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
-      if (!(sin2_t > 1.0)) {
-        double cos_t = sqrt(1.0 - sin2_t);
-        V3 direction = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
-        want_refract = true;
-        refract_ray = Ray{under_point, direction};
+    if (MODE != 0) {
+      k_reflective = m.reflective;
+      k_transparency = m.transparency;
+      // reflected_color (src/world.rs:142-159)
+      if (remaining != 0 && (m.flags & 1)) {
+        want_reflect = true;
+        reflect_ray = Ray{over_point, reflect(ray.d, normalv)};
+      }
+      double n1 = 1.0, n2 = 1.0;
+      if (m.flags & 8) {  // n1 / n2 are consumed: refraction or Schlick (src/intersect.rs:191-234)
+        ContainerQuery C;
+        C.init(leaf);
+        traverse<ContainerQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, C, st, ct);
+        double ri_hit = m.refractive_index;
+        double ri_other = C.other_leaf >= 0 ? S.materials[S.leaves[C.other_leaf].material].refractive_index : 1.0;
+        if (C.hit_inside) {
+          bool hit_last = C.other_leaf < 0 || C.hit_key > C.other_key ||
+                          (C.hit_key == C.other_key && C.hit_leaf > C.other_leaf);
+          n1 = hit_last ? ri_hit : ri_other;
+          n2 = ri_other;
+        } else {
+          n1 = ri_other;
+          n2 = ri_hit;
+        }
+      }
+      // refracted_color (src/world.rs:181-215)
+      if (remaining != 0 && (m.flags & 2)) {
+        double n_ratio = n1 / n2;
+        double cos_i = dot(eyev, normalv);
+        double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+        if (!(sin2_t > 1.0)) {
+          double cos_t = sqrt(1.0 - sin2_t);
+          V3 under_point = point - normalv * FEQ_EPSILON;
+          V3 direction = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
+          want_refract = true;
+          refract_ray = Ray{under_point, direction};
+        }
+      }
+      if (m.flags & 4) {  // schlick (src/intersect.rs:240-260)
+        double cosv = dot(eyev, normalv);
+        bool total = false;
+        if (n1 > n2) {
+          double nn = n1 / n2;
+          double sin2_t = (nn * nn) * (1.0 - cosv * cosv);
+          if (sin2_t > 1.0) total = true;
+          else cosv = sqrt(1.0 - sin2_t);
+        }
+        if (total) {
+          reflectance = 1.0;
+        } else {
+          double q = (n1 - n2) / (n1 + n2);
+          double r0 = q * q;
+          double x = 1.0 - cosv;
+          double x2 = x * x;
+          reflectance = r0 + (1.0 - r0) * (x * (x2 * x2));  // powi(5)
+        }
+        flags = 3u;
       }
     }
-    if (m.flags & 4) {  // schlick (src/intersect.rs:240-260)
-      double cosv = dot(eyev, normalv);
-      double reflectance;
-      bool total = false;
-      if (n1 > n2) {
-        double nn = n1 / n2;
-        double sin2_t = (nn * nn) * (1.0 - cosv * cosv);
-        if (sin2_t > 1.0) total = true;
-        else cosv = sqrt(1.0 - sin2_t);
+  }
+
+  if (MODE != 0) {
+    // next generation: one atomic per wave that has something to append
+    uint32_t child_reflect = REF_NONE, child_refract = REF_NONE;
+    uint32_t ri = wave_append(next_count, want_reflect);
+    if (want_reflect && ri < next_capacity) {
+      next.ox[ri] = reflect_ray.o.x; next.oy[ri] = reflect_ray.o.y; next.oz[ri] = reflect_ray.o.z;
+      next.dx[ri] = reflect_ray.d.x; next.dy[ri] = reflect_ray.d.y; next.dz[ri] = reflect_ray.d.z;
+      child_reflect = ri;
+    }
+    uint32_t ti = wave_append(next_count, want_refract);
+    if (want_refract && ti < next_capacity) {
+      next.ox[ti] = refract_ray.o.x; next.oy[ti] = refract_ray.o.y; next.oz[ti] = refract_ray.o.z;
+      next.dx[ti] = refract_ray.d.x; next.dy[ti] = refract_ray.d.y; next.dz[ti] = refract_ray.d.z;
+      child_refract = ti;
+    }
+    if (i < n) {
+      g.flags[i] = flags;
+      g.leaf[i] = leaf;
+      g.child_reflect[i] = child_reflect;
+      g.child_refract[i] = child_refract;
+      if (hit) {
+        g.t[i] = Q.best_t;
+        g.reflective[i] = k_reflective;
+        g.transparency[i] = k_transparency;
+        g.reflectance[i] = reflectance;
       }
-      if (total) {
-        reflectance = 1.0;
-      } else {
-        double q = (n1 - n2) / (n1 + n2);
-        double r0 = q * q;
-        double x = 1.0 - cosv;
-        double x2 = x * x;
-        reflectance = r0 + (1.0 - r0) * (x * (x2 * x2));  // powi(5)
-      }
-      g.reflectance[i] = reflectance;
-      g.flags[i] = 3u;
     }
   }
-  // queues: shadow rays of this generation, rays of the next generation
-  uint32_t sq = wave_append(shadow_count, hit);
-  if (hit) g.shadow_queue[sq] = i;
-  uint32_t ri = wave_append(next_count, want_reflect);
-  if (want_reflect && ri < next_capacity) {
-    next.ox[ri] = reflect_ray.o.x; next.oy[ri] = reflect_ray.o.y; next.oz[ri] = reflect_ray.o.z;
-    next.dx[ri] = reflect_ray.d.x; next.dy[ri] = reflect_ray.d.y; next.dz[ri] = reflect_ray.d.z;
-    next.leaf[ri] = -1;
-    g.child_reflect[i] = ri;
+
+  // World::is_shadowed (src/world.rs:123-137), then the in_shadow branch of lighting
+  double out_r = 0.0, out_g = 0.0, out_b = 0.0;  // World::color_at: no hit => black
+  if (hit) {
+    V3 lightpos = v3(S.light_position[0], S.light_position[1], S.light_position[2]);
+    V3 v = lightpos - over_point;
+    ShadowQuery SQ;
+    SQ.distance = magnitude(v);
+    SQ.found = false;
+    Ray shadow_ray{over_point, normalize(v)};
+    traverse<ShadowQuery, LdsStack<STACK, BLOCK>, COUNT>(S, shadow_ray, SQ, st, cs);
+    out_r = SQ.found ? ar : lr;
+    out_g = SQ.found ? ag : lg;
+    out_b = SQ.found ? ab : lb;
   }
-  uint32_t ti = wave_append(next_count, want_refract);
-  if (want_refract && ti < next_capacity) {
-    next.ox[ti] = refract_ray.o.x; next.oy[ti] = refract_ray.o.y; next.oz[ti] = refract_ray.o.z;
-    next.dx[ti] = refract_ray.d.x; next.dy[ti] = refract_ray.d.y; next.dz[ti] = refract_ray.d.z;
-    next.leaf[ti] = -1;
-    g.child_refract[i] = ti;
+  if (MODE == 0) {
+    if (active) write_pixel(img, pixel, out_r, out_g, out_b, leaf);
+  } else if (i < n) {
+    g.cr[i] = out_r; g.cg[i] = out_g; g.cb[i] = out_b;
   }
-  // ray statistics: [4] shaded hits, [5] reflection rays, [6] refraction rays
+
+  // ray statistics, one add per wave and kind, spread over STAT_SLOTS addresses
   unsigned long long hm = __ballot(hit), rm = __ballot(want_reflect), fm = __ballot(want_refract);
   if ((threadIdx.x & 63) == 0) {
-    if (hm) atomicAdd(&stats[4], (unsigned long long)__popcll(hm));
-    if (rm) atomicAdd(&stats[5], (unsigned long long)__popcll(rm));
-    if (fm) atomicAdd(&stats[6], (unsigned long long)__popcll(fm));
+    uint32_t slot = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % STAT_SLOTS;
+    if (hm) atomicAdd(&stats[STAT_RAYS + 0 * STAT_SLOTS + slot], (unsigned long long)__popcll(hm));
+    if (rm) atomicAdd(&stats[STAT_RAYS + 1 * STAT_SLOTS + slot], (unsigned long long)__popcll(rm));
+    if (fm) atomicAdd(&stats[STAT_RAYS + 2 * STAT_SLOTS + slot], (unsigned long long)__popcll(fm));
   }
-}
-
-// World::is_shadowed (src/world.rs:123-137) for every queued hit, then the
-// in_shadow branch of lighting (src/light.rs:144-146).
-template <int STACK, bool COUNT>
-__global__ void __launch_bounds__(BLOCK)
-    k_shadow(SceneDev S, GenView g, const uint32_t* shadow_count, unsigned long long* counters) {
-  __shared__ uint32_t lds[STACK * BLOCK];
-  uint32_t q = blockIdx.x * BLOCK + threadIdx.x;
-  Counters cnt = {0, 0, 0, 0};
-  if (q < *shadow_count) {
-    uint32_t i = g.shadow_queue[q];
-    LdsStack<STACK, BLOCK> st;
-    st.init(lds);
-    V3 p = v3(g.px[i], g.py[i], g.pz[i]);
-    V3 lightpos = v3(S.light_position[0], S.light_position[1], S.light_position[2]);
-    V3 v = lightpos - p;
-    ShadowQuery Q;
-    Q.distance = magnitude(v);
-    Q.found = false;
-    Ray ray{p, normalize(v)};
-    traverse<ShadowQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, Q, st, cnt);
-    if (Q.found) {
-      g.cr[i] = g.ar[i]; g.cg[i] = g.ag[i]; g.cb[i] = g.ab[i];
-    } else {
-      g.cr[i] = g.lr[i]; g.cg[i] = g.lg[i]; g.cb[i] = g.lb[i];
-    }
+  if (COUNT) {
+    flush_counters(ct, stats);
+    flush_counters(cs, stats + 4);
   }
-  if (COUNT) flush_counters(cnt, counters);
 }
 
 // shade_hit's final expression (src/world.rs:236-245), children first.
@@ -879,31 +974,13 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(GenView g, uint32_t n, GenVie
   }
 }
 
-// Canvas::save quantisation (src/canvas.rs:60-62): ceil(clamp(c * 255, 0, 255)); NaN -> 0
-DEV uint8_t quantise(double c) {
-  double v = c * 255.0;
-  if (v < 0.0) v = 0.0;
-  else if (v > 255.0) v = 255.0;
-  v = ceil(v);
-  return (v == v) ? (uint8_t)v : (uint8_t)0;
-}
-
 __global__ void __launch_bounds__(BLOCK)
-    k_output_image(GenView g, uint32_t n, CameraDev cam, const uint32_t* tiles, uint32_t tiles_x, uint8_t* rgb8,
-                   double* rgb64, int32_t* hit_leaf) {
+    k_output_image(GenView g, uint32_t n, CameraDev cam, const uint32_t* tiles, uint32_t tiles_x, ImageOut img) {
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t x, y;
   if (!ray_pixel(tiles, tiles_x, cam, i, x, y)) return;
-  size_t p = (size_t)y * cam.hsize + x;
-  double r = g.cr[i], gg = g.cg[i], b = g.cb[i];
-  if (rgb64) {
-    rgb64[p * 3 + 0] = r; rgb64[p * 3 + 1] = gg; rgb64[p * 3 + 2] = b;
-  }
-  if (rgb8) {
-    rgb8[p * 3 + 0] = quantise(r); rgb8[p * 3 + 1] = quantise(gg); rgb8[p * 3 + 2] = quantise(b);
-  }
-  if (hit_leaf) hit_leaf[p] = g.leaf[i];
+  write_pixel(img, (size_t)y * cam.hsize + x, g.cr[i], g.cg[i], g.cb[i], g.leaf[i]);
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -918,10 +995,27 @@ __global__ void __launch_bounds__(BLOCK)
   if (t) t[i] = l >= 0 ? g.t[i] : NAN;
 }
 
+// World::intersect + Intersections::hit only (rt_intersect_hit).
+template <int STACK>
+__global__ void __launch_bounds__(BLOCK) k_intersect(SceneDev S, GenView g, uint32_t n) {
+  __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  LdsStack<STACK, BLOCK> st;
+  st.init(lds);
+  Counters cnt = {0, 0, 0, 0};
+  ClosestQuery Q;
+  Q.init();
+  traverse<ClosestQuery, LdsStack<STACK, BLOCK>, false>(S, load_ray(g, i), Q, st, cnt);
+  bool hit = Q.best_leaf != 0x7FFFFFFF;
+  g.leaf[i] = hit ? Q.best_leaf : -1;
+  if (hit) g.t[i] = Q.best_t;
+}
+
 // World::is_shadowed for caller-supplied points.
 template <int STACK>
 __global__ void __launch_bounds__(BLOCK) k_points_shadowed(SceneDev S, uint32_t n, const double* pts, uint8_t* out) {
-  __shared__ uint32_t lds[STACK * BLOCK];
+  __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   LdsStack<STACK, BLOCK> st;
@@ -946,14 +1040,6 @@ __global__ void __launch_bounds__(BLOCK) k_pixel_rays(CameraDev cam, uint32_t n,
   o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_export_rays(GenView g, uint32_t n, double* rays6) {
-  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  double* r = rays6 + (size_t)i * 6;
-  r[0] = g.ox[i]; r[1] = g.oy[i]; r[2] = g.oz[i];
-  r[3] = g.dx[i]; r[4] = g.dy[i]; r[5] = g.dz[i];
-}
-
 // ---------------------------------------------------------------------------
 // host side: scene object
 // ---------------------------------------------------------------------------
@@ -965,8 +1051,8 @@ struct GenBuf {
   GenView view;
 };
 
-constexpr int N_DOUBLE_ARRAYS = 26;
-constexpr int N_U32_ARRAYS = 5;
+constexpr int N_DOUBLE_ARRAYS = 13;
+constexpr int N_U32_ARRAYS = 4;
 
 size_t gen_bytes(size_t cap) {
   size_t c = (cap + 63) & ~(size_t)63;
@@ -977,16 +1063,14 @@ void carve(GenBuf& b) {
   size_t c = (b.capacity + 63) & ~(size_t)63;
   double* d = (double*)b.slab;
   GenView& v = b.view;
-  double** dptr[N_DOUBLE_ARRAYS] = {&v.ox, &v.oy, &v.oz, &v.dx, &v.dy, &v.dz, &v.t,  &v.u,  &v.v,  &v.n1,
-                                    &v.n2, &v.px, &v.py, &v.pz, &v.ar, &v.ag, &v.ab, &v.lr, &v.lg, &v.lb,
-                                    &v.cr, &v.cg, &v.cb, &v.reflective, &v.transparency, &v.reflectance};
+  double** dptr[N_DOUBLE_ARRAYS] = {&v.ox, &v.oy, &v.oz, &v.dx, &v.dy, &v.dz, &v.cr,
+                                    &v.cg, &v.cb, &v.reflective, &v.transparency, &v.reflectance, &v.t};
   for (int k = 0; k < N_DOUBLE_ARRAYS; k++) *dptr[k] = d + (size_t)k * c;
   uint32_t* u = (uint32_t*)(d + (size_t)N_DOUBLE_ARRAYS * c);
-  v.leaf = (int32_t*)u;
-  v.child_reflect = u + c;
-  v.child_refract = u + 2 * c;
-  v.flags = u + 3 * c;
-  v.shadow_queue = u + 4 * c;
+  v.child_reflect = u;
+  v.child_refract = u + c;
+  v.flags = u + 2 * c;
+  v.leaf = (int32_t*)(u + 3 * c);
 }
 
 }  // namespace
@@ -1000,15 +1084,16 @@ struct rt_scene {
   double build_seconds = 0;
   int stack_need = 1;
   int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
-  GenBuf gens[MAX_GENERATIONS];
-  uint32_t* d_counts = nullptr;             // [gen][2]: shadow queue length, next generation length
-  unsigned long long* d_stats = nullptr;    // 16 counters: closest-hit [0..3], shade [4..6], shadow [8..11]
-  uint32_t* h_counts = nullptr;             // pinned mirror
+  GenBuf gens[MAX_GENERATIONS + 1];
+  uint32_t* d_counts = nullptr;           // [gen]: length of the next generation
+  unsigned long long* d_stats = nullptr;  // STAT_WORDS counters
+  uint32_t* h_counts = nullptr;           // pinned mirrors
   unsigned long long* h_stats = nullptr;
   uint32_t* d_tiles = nullptr;
   size_t tiles_capacity = 0;
   std::vector<uint32_t> h_tiles;
-  hipEvent_t ev[4 * MAX_GENERATIONS] = {};
+  uint32_t tiles_key[4] = {0, 0, 0, 0};  // hsize, vsize, part, n_parts of the uploaded tile table
+  hipEvent_t ev[2 * MAX_GENERATIONS] = {};
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -1169,18 +1254,14 @@ struct SceneBuild {
     }
   }
 
-  // Builds the subtree of gate gi; returns depth needed below it and its box.
-  int build_gate(int gi, BuildItem* out_item, bool* has_item) {
+  // Builds the subtree of gate gi and its item for the enclosing level.
+  void build_gate(int gi, BuildItem* out_item, bool* has_item) {
     std::vector<BuildItem> items;
-    int child_depth = 0;
     for (int c : gate_children[gi]) {
       BuildItem it{};
       bool ok = false;
-      int dep = build_gate(c, &it, &ok);
-      if (ok) {
-        items.push_back(it);
-        child_depth = std::max(child_depth, dep);
-      }
+      build_gate(c, &it, &ok);
+      if (ok) items.push_back(it);
     }
     leaf_items(gate_leaves[gi], items);
     const rt_gate& G = d->gates[gi];
@@ -1191,10 +1272,20 @@ struct SceneBuild {
       g.bmax[a] = G.bmax[a];
     }
     g.parent = G.parent;
+    g.pad = 0;
     double lo[3], hi[3];
-    bvh.max_depth = 0;
     g.root = bvh.build(items, lo, hi);
-    int own = bvh.max_depth;
+    if ((size_t)gi >= bvh.gate_need.size()) bvh.gate_need.resize(gi + 1, 0);
+    bvh.gate_need[gi] = bvh.stack_need + 1;
+    // The exact test can be skipped for rays without a near-zero direction component when the
+    // group space is world space and the reference box holds everything below (boxes are padded
+    // by about 1e-7 relative, hence the tolerance).
+    bool contains = g.root != REF_NONE;
+    for (int a = 0; a < 3 && contains; a++) {
+      double tol = 1e-6 * (fabs(lo[a]) + fabs(hi[a]) + (hi[a] - lo[a])) + 1e-8;
+      if (!(G.bmin[a] <= lo[a] + tol) || !(G.bmax[a] >= hi[a] - tol)) contains = false;
+    }
+    g.skippable = (contains && is_identity(G.to_local)) ? 1u : 0u;
     *has_item = g.root != REF_NONE;
     if (*has_item) {
       out_item->kind = KIND_GATE;
@@ -1204,16 +1295,14 @@ struct SceneBuild {
         out_item->hi[a] = hi[a];
       }
     }
-    return own + 1 + child_depth;
   }
 };
 
-int pick_stack(int need) {
-  if (need <= 16) return 16;
-  if (need <= 32) return 32;
-  if (need <= 48) return 48;
-  return 64;
-}
+#ifndef RT_STACK_SMALL
+#define RT_STACK_SMALL 32
+#endif
+constexpr int STACK_SMALL = RT_STACK_SMALL;
+int pick_stack(int need) { return need <= STACK_SMALL ? STACK_SMALL : 64; }
 
 }  // namespace
 
@@ -1300,23 +1389,26 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     else b.gate_leaves[d->leaves[i].gate].push_back(i);
   }
   std::vector<BuildItem> items;
-  int child_depth = 0;
   for (int gi : b.top_gates) {
     BuildItem it{};
     bool ok = false;
-    int dep = b.build_gate(gi, &it, &ok);
-    if (ok) {
-      items.push_back(it);
-      child_depth = std::max(child_depth, dep);
-    }
+    b.build_gate(gi, &it, &ok);
+    if (ok) items.push_back(it);
   }
   b.leaf_items(b.top_leaves, items);
   double lo[3], hi[3];
-  b.bvh.max_depth = 0;
   uint32_t root = b.bvh.build(items, lo, hi);
-  s->stack_need = b.bvh.max_depth + 1 + child_depth + 1;
+  s->stack_need = b.bvh.stack_need + 2;
   if (s->stack_need > TRAVERSAL_STACK)
     return fail(RT_ERR_UNSUPPORTED, "scene hierarchy is deeper than the traversal stack");
+  if (getenv("RT_AMD_DEBUG")) {
+    int occ = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_generation<STACK_SMALL, false, 0>, BLOCK, 0);
+    fprintf(stderr, "[rt_amd] k_generation<%d> blocks of %d per CU (occupancy API): %d\n", STACK_SMALL, BLOCK, occ);
+    fprintf(stderr, "[rt_amd] leaves=%d gates=%d nodes=%zu tris=%zu quads=%zu unbounded=%zu stack_need=%d\n", d->n_leaves,
+            d->n_gates, b.bvh.nodes.size(), b.bvh.tri_order.size(), b.bvh.quad_order.size(), b.unbounded.size(),
+            s->stack_need);
+  }
 
   std::vector<TriIsect> tris(b.bvh.tri_order.size());
   for (size_t i = 0; i < tris.size(); i++) tris[i] = b.tri_src[b.bvh.tri_order[i]];
@@ -1396,10 +1488,10 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     s->dev.light_position[a] = d->light.position[a];
   }
 
-  HIP_TRY(hipMalloc((void**)&s->d_counts, MAX_GENERATIONS * 2 * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc((void**)&s->d_stats, 16 * sizeof(unsigned long long)));
-  HIP_TRY(hipHostMalloc((void**)&s->h_counts, MAX_GENERATIONS * 2 * sizeof(uint32_t), hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void**)&s->h_stats, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+  HIP_TRY(hipMalloc((void**)&s->d_counts, (MAX_GENERATIONS + 1) * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc((void**)&s->d_stats, STAT_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_counts, (MAX_GENERATIONS + 1) * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
   for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
   return RT_OK;
 }
@@ -1457,103 +1549,37 @@ int ensure_gen(rt_scene* s, int g, size_t cap) {
 
 inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
 
-template <bool COUNT>
-void launch_trace(rt_scene* s, const GenView& g, uint32_t n) {
-  dim3 grid(blocks_for(n)), block(BLOCK);
-  switch (pick_stack(s->stack_need)) {
-    case 16: hipLaunchKernelGGL((k_trace<16, COUNT>), grid, block, 0, s->stream, s->dev, g, n, s->d_stats); break;
-    case 32: hipLaunchKernelGGL((k_trace<32, COUNT>), grid, block, 0, s->stream, s->dev, g, n, s->d_stats); break;
-    case 48: hipLaunchKernelGGL((k_trace<48, COUNT>), grid, block, 0, s->stream, s->dev, g, n, s->d_stats); break;
-    default: hipLaunchKernelGGL((k_trace<64, COUNT>), grid, block, 0, s->stream, s->dev, g, n, s->d_stats); break;
+struct GenLaunch {
+  GenView cur, next;
+  uint32_t n, next_capacity;
+  int remaining;
+  uint32_t* next_count;
+  CameraDev cam;
+  const uint32_t* tiles;
+  uint32_t tiles_x;
+  ImageOut img;
+};
+
+template <int STACK, bool COUNT>
+void launch_generation_mode(rt_scene* s, int mode, const GenLaunch& a) {
+  dim3 grid(blocks_for(a.n)), block(BLOCK);
+#define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_capacity, a.remaining, a.next_count, s->d_stats, a.cam, a.tiles, a.tiles_x, a.img
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0>), grid, block, 0, s->stream, RT_GEN_ARGS); break;
+    case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1>), grid, block, 0, s->stream, RT_GEN_ARGS); break;
+    default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2>), grid, block, 0, s->stream, RT_GEN_ARGS); break;
   }
-}
-template <bool COUNT>
-void launch_shadow(rt_scene* s, const GenView& g, uint32_t n, const uint32_t* count) {
-  dim3 grid(blocks_for(n)), block(BLOCK);
-  switch (pick_stack(s->stack_need)) {
-    case 16: hipLaunchKernelGGL((k_shadow<16, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats + 8); break;
-    case 32: hipLaunchKernelGGL((k_shadow<32, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats + 8); break;
-    case 48: hipLaunchKernelGGL((k_shadow<48, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats + 8); break;
-    default: hipLaunchKernelGGL((k_shadow<64, COUNT>), grid, block, 0, s->stream, s->dev, g, count, s->d_stats + 8); break;
-  }
+#undef RT_GEN_ARGS
 }
 
-// Runs trace/shade/shadow over generation 0 (already filled with n0 rays) and
-// its descendants, then resolves colours back into generation 0.
-int run_generations(rt_scene* s, uint32_t n0, int remaining0, uint32_t flags, bool shade, rt_stats* stats) {
-  const bool count = (flags & RT_FLAG_COUNTERS) != 0;
-  HIP_TRY(hipMemsetAsync(s->d_counts, 0, MAX_GENERATIONS * 2 * sizeof(uint32_t), s->stream));
-  HIP_TRY(hipMemsetAsync(s->d_stats, 0, 16 * sizeof(unsigned long long), s->stream));
-  uint32_t n[MAX_GENERATIONS + 1] = {0};
-  n[0] = n0;
-  int last = 0;
-  int ngen_max = remaining0 < 0 ? 0 : remaining0;
-  if (ngen_max > RECURSION_DEPTH) ngen_max = RECURSION_DEPTH;
-  for (int g = 0; g <= ngen_max && n[g] > 0; g++) {
-    last = g;
-    const GenView& cur = s->gens[g].view;
-    HIP_TRY(hipEventRecord(s->ev[g * 4 + 0], s->stream));
-    if (count) launch_trace<true>(s, cur, n[g]);
-    else launch_trace<false>(s, cur, n[g]);
-    HIP_TRY(hipEventRecord(s->ev[g * 4 + 1], s->stream));
-    if (!shade) break;
-    int remaining = remaining0 - g;
-    uint64_t next_cap64 = remaining > 0 ? (uint64_t)n[g] * (uint64_t)s->max_children : 0;
-    if (next_cap64 > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "too many secondary rays for one generation");
-    int rc = ensure_gen(s, g + 1 < MAX_GENERATIONS ? g + 1 : g, (size_t)next_cap64);
-    if (rc) return rc;
-    const GenView& nxt = s->gens[g + 1 < MAX_GENERATIONS ? g + 1 : g].view;
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(n[g])), dim3(BLOCK), 0, s->stream, s->dev, cur, n[g], nxt,
-                       (uint32_t)next_cap64, remaining, s->d_counts + g * 2, s->d_counts + g * 2 + 1, s->d_stats);
-    HIP_TRY(hipEventRecord(s->ev[g * 4 + 2], s->stream));
-    if (count) launch_shadow<true>(s, cur, n[g], s->d_counts + g * 2);
-    else launch_shadow<false>(s, cur, n[g], s->d_counts + g * 2);
-    HIP_TRY(hipEventRecord(s->ev[g * 4 + 3], s->stream));
-    if (remaining > 0 && s->max_children > 0) {
-      HIP_TRY(hipMemcpyAsync(s->h_counts + g * 2, s->d_counts + g * 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                             s->stream));
-      HIP_TRY(hipStreamSynchronize(s->stream));
-      n[g + 1] = std::min<uint32_t>(s->h_counts[g * 2 + 1], (uint32_t)next_cap64);
-    }
+void launch_generation(rt_scene* s, int mode, bool count, const GenLaunch& a) {
+  if (pick_stack(s->stack_need) == STACK_SMALL) {
+    if (count) launch_generation_mode<STACK_SMALL, true>(s, mode, a);
+    else launch_generation_mode<STACK_SMALL, false>(s, mode, a);
+  } else {
+    if (count) launch_generation_mode<64, true>(s, mode, a);
+    else launch_generation_mode<64, false>(s, mode, a);
   }
-  if (shade) {
-    for (int g = last - 1; g >= 0; g--)
-      hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n[g])), dim3(BLOCK), 0, s->stream, s->gens[g].view, n[g],
-                         s->gens[g + 1].view);
-  }
-  HIP_TRY(hipGetLastError());
-  if (stats) {
-    HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    stats->node_visits = s->h_stats[0];
-    stats->tri_tests = s->h_stats[1];
-    stats->quadric_tests = s->h_stats[2];
-    stats->gate_tests = s->h_stats[3];
-    stats->shaded_hits = s->h_stats[4];
-    stats->shadow = s->h_stats[4];
-    stats->reflect = s->h_stats[5];
-    stats->refract = s->h_stats[6];
-    stats->shadow_node_visits = s->h_stats[8];
-    stats->shadow_tri_tests = s->h_stats[9];
-    stats->shadow_quadric_tests = s->h_stats[10];
-    stats->shadow_gate_tests = s->h_stats[11];
-    stats->trace_ms = 0;
-    stats->shadow_ms = 0;
-    stats->trace_launches = 0;
-    stats->shadow_launches = 0;
-    for (int g = 0; g <= last; g++) {
-      float ms = 0;
-      HIP_TRY(hipEventElapsedTime(&ms, s->ev[g * 4 + 0], s->ev[g * 4 + 1]));
-      stats->trace_ms += ms;
-      stats->trace_launches++;
-      if (shade) {
-        HIP_TRY(hipEventElapsedTime(&ms, s->ev[g * 4 + 2], s->ev[g * 4 + 3]));
-        stats->shadow_ms += ms;
-        stats->shadow_launches++;
-      }
-    }
-  }
-  return RT_OK;
 }
 
 CameraDev camera_dev(const rt_camera* c) {
@@ -1565,6 +1591,97 @@ CameraDev camera_dev(const rt_camera* c) {
   cd.pixel_size = c->pixel_size;
   copy3x4(cd.inv, c->inv);
   return cd;
+}
+
+struct PipelineIn {
+  uint32_t n0 = 0;
+  int remaining0 = RECURSION_DEPTH;
+  uint32_t flags = 0;
+  bool camera = false;  // generation 0 from the camera (else from gens[0] ray arrays)
+  CameraDev cam{};
+  const uint32_t* tiles = nullptr;
+  uint32_t tiles_x = 0;
+  ImageOut img{nullptr, nullptr, nullptr};
+};
+
+// Runs the generations, resolves colours back into generation 0 and, for camera
+// rays, writes the image.  Fills the device-side fields of stats.
+int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
+  const bool count = (in.flags & RT_FLAG_COUNTERS) != 0;
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), s->stream));
+  int max_gen = std::min(std::max(in.remaining0, 0), RECURSION_DEPTH);
+  if (s->max_children == 0) max_gen = 0;
+  const bool direct = in.camera && max_gen == 0;  // every pixel is final after generation 0
+  if (max_gen > 0) HIP_TRY(hipMemsetAsync(s->d_counts, 0, (MAX_GENERATIONS + 1) * sizeof(uint32_t), s->stream));
+  uint32_t n[MAX_GENERATIONS + 2] = {0};
+  n[0] = in.n0;
+  int last = 0;
+  for (int g = 0; g <= max_gen && n[g] > 0; g++) {
+    last = g;
+    int remaining = in.remaining0 - g;
+    if (remaining < 0) remaining = 0;
+    uint64_t next_cap = (g < max_gen) ? (uint64_t)n[g] * (uint64_t)s->max_children : 0;
+    if (next_cap > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "too many secondary rays for one generation");
+    int rc;
+    if (!direct && (rc = ensure_gen(s, g, n[g]))) return rc;
+    if ((rc = ensure_gen(s, g + 1, (size_t)next_cap))) return rc;
+    GenLaunch a;
+    a.cur = s->gens[g].view;
+    a.next = s->gens[g + 1].view;
+    a.n = n[g];
+    a.next_capacity = (uint32_t)next_cap;
+    a.remaining = (g < max_gen) ? remaining : 0;
+    a.next_count = s->d_counts + g;
+    a.cam = in.cam;
+    a.tiles = in.tiles;
+    a.tiles_x = in.tiles_x;
+    a.img = in.img;
+    int mode = (g == 0 && in.camera) ? (direct ? 0 : 1) : 2;
+    HIP_TRY(hipEventRecord(s->ev[g * 2 + 0], s->stream));
+    launch_generation(s, mode, count, a);
+    HIP_TRY(hipEventRecord(s->ev[g * 2 + 1], s->stream));
+    if (g < max_gen) {
+      HIP_TRY(hipMemcpyAsync(s->h_counts + g, s->d_counts + g, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      n[g + 1] = std::min<uint32_t>(s->h_counts[g], (uint32_t)next_cap);
+    }
+  }
+  for (int g = last - 1; g >= 0; g--)
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n[g])), dim3(BLOCK), 0, s->stream, s->gens[g].view, n[g],
+                       s->gens[g + 1].view);
+  if (in.camera && !direct)
+    hipLaunchKernelGGL(k_output_image, dim3(blocks_for(in.n0)), dim3(BLOCK), 0, s->stream, s->gens[0].view, in.n0,
+                       in.cam, in.tiles, in.tiles_x, in.img);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                         s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (stats) {
+    unsigned long long sums[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++)
+      for (int j = 0; j < STAT_SLOTS; j++) sums[k] += s->h_stats[STAT_RAYS + k * STAT_SLOTS + j];
+    stats->shadow = sums[0];
+    stats->reflect = sums[1];
+    stats->refract = sums[2];
+    stats->node_visits = s->h_stats[0];
+    stats->tri_tests = s->h_stats[1];
+    stats->quadric_tests = s->h_stats[2];
+    stats->gate_tests = s->h_stats[3];
+    stats->shadow_node_visits = s->h_stats[4];
+    stats->shadow_tri_tests = s->h_stats[5];
+    stats->shadow_quadric_tests = s->h_stats[6];
+    stats->shadow_gate_tests = s->h_stats[7];
+    stats->kernel_ms = 0;
+    stats->kernel_launches = 0;
+    stats->generations = (uint64_t)last + 1;
+    for (int g = 0; g <= last; g++) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, s->ev[g * 2 + 0], s->ev[g * 2 + 1]));
+      stats->kernel_ms += ms;
+      stats->kernel_launches++;
+    }
+  }
+  return RT_OK;
 }
 
 int stage_reserve(rt_scene* s, size_t bytes) {
@@ -1590,38 +1707,40 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   if (!affine(camera->inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) camera transform");
   auto w0 = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
+  if (stats) memset(stats, 0, sizeof(*stats));
   uint32_t tiles_x = (camera->hsize + TILE - 1) / TILE, tiles_y = (camera->vsize + TILE - 1) / TILE;
-  s->h_tiles.clear();
-  for (uint32_t ty = 0; ty < tiles_y; ty++)
-    for (uint32_t tx = 0; tx < tiles_x; tx++)
-      if ((int)((tx + ty) % (uint32_t)n_parts) == part) s->h_tiles.push_back(ty * tiles_x + tx);
+  const uint32_t key[4] = {camera->hsize, camera->vsize, (uint32_t)part, (uint32_t)n_parts};
+  if (memcmp(key, s->tiles_key, sizeof(key)) != 0) {
+    s->h_tiles.clear();
+    for (uint32_t ty = 0; ty < tiles_y; ty++)
+      for (uint32_t tx = 0; tx < tiles_x; tx++)
+        if ((int)((tx + ty) % (uint32_t)n_parts) == part) s->h_tiles.push_back(ty * tiles_x + tx);
+    if (s->tiles_capacity < s->h_tiles.size()) {
+      if (s->d_tiles) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipFree(s->d_tiles));
+        s->d_tiles = nullptr;
+      }
+      HIP_TRY(hipMalloc((void**)&s->d_tiles, s->h_tiles.size() * sizeof(uint32_t)));
+      s->tiles_capacity = s->h_tiles.size();
+    }
+    if (!s->h_tiles.empty())
+      HIP_TRY(hipMemcpy(s->d_tiles, s->h_tiles.data(), s->h_tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    memcpy(s->tiles_key, key, sizeof(key));
+  }
   uint64_t n64 = (uint64_t)s->h_tiles.size() * TILE_PIXELS;
   if (n64 > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "canvas part exceeds 2^32 rays");
-  uint32_t n = (uint32_t)n64;
-  if (stats) memset(stats, 0, sizeof(*stats));
-  if (n == 0) return RT_OK;
-  if (s->tiles_capacity < s->h_tiles.size()) {
-    if (s->d_tiles) {
-      HIP_TRY(hipStreamSynchronize(s->stream));
-      HIP_TRY(hipFree(s->d_tiles));
-      s->d_tiles = nullptr;
-    }
-    HIP_TRY(hipMalloc((void**)&s->d_tiles, s->h_tiles.size() * sizeof(uint32_t)));
-    s->tiles_capacity = s->h_tiles.size();
-  }
-  HIP_TRY(hipMemcpyAsync(s->d_tiles, s->h_tiles.data(), s->h_tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                         s->stream));
-  int rc = ensure_gen(s, 0, n);
+  if (n64 == 0) return RT_OK;
+  PipelineIn in;
+  in.n0 = (uint32_t)n64;
+  in.flags = flags;
+  in.camera = true;
+  in.cam = camera_dev(camera);
+  in.tiles = s->d_tiles;
+  in.tiles_x = tiles_x;
+  in.img = ImageOut{rgb8_dev, rgb64_dev, hit_leaf_dev};
+  int rc = run_pipeline(s, in, stats);
   if (rc) return rc;
-  CameraDev cam = camera_dev(camera);
-  hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, n, cam, s->d_tiles,
-                     tiles_x);
-  rc = run_generations(s, n, RECURSION_DEPTH, flags, true, stats);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_output_image, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, n, cam,
-                     s->d_tiles, tiles_x, rgb8_dev, rgb64_dev, hit_leaf_dev);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(s->stream));
   if (stats) {
     uint64_t valid = 0;
     for (uint32_t t : s->h_tiles) {
@@ -1663,9 +1782,7 @@ extern "C" int rt_ray_for_pixel(rt_scene* s, const rt_camera* camera, uint64_t n
   HIP_TRY(hipSetDevice(s->device));
   if (n == 0) return RT_OK;
   if (n > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "too many pixels in one call");
-  int rc = ensure_gen(s, 0, (size_t)n);
-  if (rc) return rc;
-  rc = stage_reserve(s, n * 6 * sizeof(double) + n * 2 * sizeof(uint32_t));
+  int rc = stage_reserve(s, n * 6 * sizeof(double) + n * 2 * sizeof(uint32_t));
   if (rc) return rc;
   double* d_rays = (double*)s->stage;
   uint32_t* d_xy = (uint32_t*)(d_rays + n * 6);
@@ -1701,9 +1818,13 @@ extern "C" int rt_color_at(rt_scene* s, uint64_t n, const double* rays6, int rem
   auto w0 = std::chrono::steady_clock::now();
   int rc = load_user_rays(s, n, rays6);
   if (rc) return rc;
-  rc = run_generations(s, (uint32_t)n, remaining, flags, true, stats);
+  PipelineIn in;
+  in.n0 = (uint32_t)n;
+  in.remaining0 = remaining;
+  in.flags = flags;
+  rc = run_pipeline(s, in, stats);
   if (rc) return rc;
-  // rays6 staging is no longer needed: reuse the buffer for the results
+  // the staged rays are consumed: reuse the buffer for the results
   double* d_rgb = (double*)s->stage;
   int32_t* d_leaf = (int32_t*)(d_rgb + n * 3);
   hipLaunchKernelGGL(k_output_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, (uint32_t)n,
@@ -1725,12 +1846,15 @@ extern "C" int rt_intersect_hit(rt_scene* s, uint64_t n, const double* rays6, do
   if (n == 0) return RT_OK;
   int rc = load_user_rays(s, n, rays6);
   if (rc) return rc;
-  rc = run_generations(s, (uint32_t)n, 0, 0, false, nullptr);
-  if (rc) return rc;
+  dim3 grid(blocks_for(n)), block(BLOCK);
+  if (pick_stack(s->stack_need) == STACK_SMALL)
+    hipLaunchKernelGGL((k_intersect<STACK_SMALL>), grid, block, 0, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
+  else
+    hipLaunchKernelGGL((k_intersect<64>), grid, block, 0, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
   double* d_t = (double*)s->stage;
   int32_t* d_leaf = (int32_t*)(d_t + n);
-  hipLaunchKernelGGL(k_output_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, (uint32_t)n,
-                     (double*)nullptr, d_leaf, d_t);
+  hipLaunchKernelGGL(k_output_rays, grid, block, 0, s->stream, s->gens[0].view, (uint32_t)n, (double*)nullptr, d_leaf,
+                     d_t);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(leaf, d_leaf, n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
@@ -1749,12 +1873,10 @@ extern "C" int rt_is_shadowed(rt_scene* s, uint64_t n, const double* points3, ui
   uint8_t* d_out = (uint8_t*)(d_pts + n * 3);
   HIP_TRY(hipMemcpyAsync(d_pts, points3, n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
   dim3 grid(blocks_for(n)), block(BLOCK);
-  switch (pick_stack(s->stack_need)) {
-    case 16: hipLaunchKernelGGL((k_points_shadowed<16>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out); break;
-    case 32: hipLaunchKernelGGL((k_points_shadowed<32>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out); break;
-    case 48: hipLaunchKernelGGL((k_points_shadowed<48>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out); break;
-    default: hipLaunchKernelGGL((k_points_shadowed<64>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out); break;
-  }
+  if (pick_stack(s->stack_need) == STACK_SMALL)
+    hipLaunchKernelGGL((k_points_shadowed<STACK_SMALL>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
+  else
+    hipLaunchKernelGGL((k_points_shadowed<64>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(shadowed, d_out, n, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));

@@ -26,12 +26,15 @@ inline uint32_t make_run(uint32_t kind, uint32_t first, uint32_t count) {
   return (kind << 30) | ((count - 1) << 27) | first;
 }
 
-// Binary BVH node holding the world-space boxes of both children (f64).
+// 4-wide BVH node: the world-space boxes of up to four children as f32, rounded outward from the
+// f64 boxes (a box test only has to be conservative; the primitives behind it are tested in f64).
+// Plane k of axis a of child c sits at plane[k][a][c], so a ray picks its near / far planes by
+// byte offset (0 or 48) and loads four children per 16-byte load.  Empty slots hold an inverted
+// box (+inf, -inf) and REF_NONE.
 struct alignas(128) BvhNode {
-  double lo0[3], hi0[3];
-  double lo1[3], hi1[3];
-  uint32_t c0, c1;
-  uint32_t pad[6];
+  float plane[2][3][4];  // [0] = lower planes, [1] = upper planes
+  uint32_t child[4];
+  uint32_t pad[4];
 };
 static_assert(sizeof(BvhNode) == 128, "BvhNode must be one cache line");
 
@@ -53,11 +56,15 @@ static_assert(sizeof(QuadPrim) == 128, "QuadPrim must be one cache line");
 
 // One reference Group: exact bounding-box gate in group space, then its subtree.
 struct alignas(32) Gate {
-  double m[12];  // rows 0..2 of to_local
-  double bmin[3], bmax[3];
   uint32_t root;  // traversal reference of the subtree (REF_NONE when empty)
   int32_t parent;
-  uint32_t pad[2];
+  // 1 when the exact test may be skipped for a ray with no direction component below FEQ_EPSILON:
+  // the group's ray transform is the identity and its reference box contains everything under it,
+  // so for such a ray the reference's gate is an ordinary slab test that the BVH already performs.
+  uint32_t skippable;
+  uint32_t pad;
+  double m[12];  // rows 0..2 of to_local
+  double bmin[3], bmax[3];
 };
 static_assert(sizeof(Gate) == 160, "Gate layout");
 
