@@ -235,8 +235,8 @@ uint32_t BvhBuilder::collapse(uint32_t bin_ref, int* need) {
   BvhNode& out = nodes[idx];
   for (int c = 0; c < 4; c++) {
     for (int a = 0; a < 3; a++) {
-      out.plane[0][a][c] = c < n ? round_down(slots[c].lo[a]) : INFINITY;
-      out.plane[1][a][c] = c < n ? round_up(slots[c].hi[a]) : -INFINITY;
+      out.plane[a][0][c] = c < n ? round_down(slots[c].lo[a]) : INFINITY;
+      out.plane[a][1][c] = c < n ? round_up(slots[c].hi[a]) : -INFINITY;
     }
     out.child[c] = c < n ? refs[c] : REF_NONE;
     out.pad[c] = 0;

@@ -258,6 +258,7 @@ DEV bool gate_passes(const Gate& g, const Ray& world_ray) {
 // Closest hit = first finite t >= 0 of the stably sorted list
 // (src/intersect.rs:71-89); equal t resolves to the lower depth-first leaf.
 struct ClosestQuery {
+  static constexpr bool BEHIND = false;
   double best_t;
   int best_leaf;
   double u, v;
@@ -266,7 +267,6 @@ struct ClosestQuery {
     best_leaf = 0x7FFFFFFF;
     u = v = 0.0;
   }
-  DEV float lo_f() const { return 0.0f; }
   DEV float hi_f() const { return __double2float_ru(best_t); }
   DEV bool done() const { return false; }
   DEV void offer(double t, int leaf, double uu, double vv) {
@@ -285,9 +285,9 @@ struct ClosestQuery {
 
 // World::is_shadowed (src/world.rs:123-137): some finite 0 <= t < distance exists.
 struct ShadowQuery {
+  static constexpr bool BEHIND = false;
   double distance;
   bool found;
-  DEV float lo_f() const { return 0.0f; }
   DEV float hi_f() const { return __double2float_ru(distance); }
   DEV bool done() const { return found; }
   DEV void leaf_ts(int, int n, const double* t) {
@@ -304,6 +304,7 @@ struct ShadowQuery {
 // `containers` there iff it has an odd number of them, and its position in the
 // vector is decided by its largest negative t (ties: depth-first order).
 struct ContainerQuery {
+  static constexpr bool BEHIND = true;  // wants t < 0: the boxes are walked along the reversed ray
   int hit_leaf;
   bool hit_inside;
   double hit_key;
@@ -316,8 +317,7 @@ struct ContainerQuery {
     other_key = -INFINITY;
     other_leaf = -1;
   }
-  DEV float lo_f() const { return -INFINITY; }
-  DEV float hi_f() const { return 0.0f; }
+  DEV float hi_f() const { return INFINITY; }
   DEV bool done() const { return false; }
   DEV void container(int leaf, int count, double key) {
     if (!(count & 1)) return;
@@ -361,6 +361,12 @@ struct LdsStack {
   DEV void push(uint32_t r) {
     if (sp < STACK) base[(sp++) * BLOCK] = r;
   }
+  // Unconditional store, conditional advance: the slot above the top is scratch.  The host sizes
+  // the stack three entries above the deepest need, so the store never leaves the lane's column.
+  DEV void push_if(uint32_t r, bool take) {
+    base[sp * BLOCK] = r;
+    sp += take ? 1 : 0;
+  }
   DEV uint32_t pop() { return base[(--sp) * BLOCK]; }
   DEV uint32_t pop_or_none() { return sp > 0 ? base[(--sp) * BLOCK] : REF_NONE; }
   DEV bool empty() const { return sp == 0; }
@@ -377,6 +383,10 @@ struct LdsStack {
   DEV void push(uint32_t r) {
     if (sp < STACK) slot[sp++] = r;
   }
+  DEV void push_if(uint32_t r, bool take) {
+    slot[sp] = r;
+    sp += take ? 1 : 0;
+  }
   DEV uint32_t pop() { return slot[--sp]; }
   DEV uint32_t pop_or_none() { return sp > 0 ? slot[--sp] : REF_NONE; }
   DEV bool empty() const { return sp == 0; }
@@ -385,37 +395,41 @@ struct LdsStack {
 #define RT_STACK_LDS(n) 1
 #endif
 
-// What a ray needs for the f32 box tests: t(plane) = plane * inv - origin * inv per axis, the near
-// plane of an axis being the lower one when inv >= 0.  The f32 evaluation of that expression is off
-// by at most 2^-23 * (|origin * inv| + |t|) (rounding of inv, of origin * inv and of the fused
-// multiply-add), so the near value is lowered and the far value raised by 2^-22 of both terms: the
-// interval only ever grows, and a box test can pass wrongly but never fail wrongly.
+// What a ray needs for the f32 box tests.  Per axis t(plane) = (plane - origin) / direction; the
+// near plane of an axis is the lower one when the direction is positive.  Only t >= 0 matters
+// (queries behind the origin walk the reversed ray), so a test stays conservative when every near
+// value is computed too small and every far value too large:
+//   inv          1 / direction from v_rcp_f32 (relative error below 2^-22); origin * inv is formed
+//                with that same inv, so the error of inv only scales t
+//   near / far   inv and origin * inv scaled by (1 -/+ 2^-20), which covers the error of inv and the
+//                rounding of the fused multiply-add (2^-24 |t| each)
+//   c_n / c_f    additionally moved by 2^-22 |origin * inv| and rounded outward: covers the f32
+//                rounding of inv and of origin * inv, which are relative to |origin * inv|, not to t
+// A box test can therefore pass wrongly but never fail wrongly.
 struct RayBox {
-  float inv[3];
-  float c_near[3], c_far[3];   // origin * inv plus / minus its error bound
-  uint32_t off_near[3], off_far[3];  // byte offsets of the near / far planes of each axis in a BvhNode
-  bool tiny;                   // some |direction| component is below FEQ_EPSILON
+  float inv_n[3], c_n[3], inv_f[3], c_f[3];
+  uint32_t off_near[3];  // byte offset of the near plane of each axis in a BvhNode; far = near ^ 16
+  bool tiny;             // some |direction| component is below FEQ_EPSILON
 };
-constexpr float BOX_REL = 2.4e-7f;  // 2^-22
 
-DEV RayBox make_raybox(const Ray& r) {
+DEV RayBox make_raybox(const Ray& r, bool reversed) {
   RayBox b;
   const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
   b.tiny = false;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    double dir = d[a];
+    double dir = reversed ? -d[a] : d[a];
     if (fabs(dir) < FEQ_EPSILON) b.tiny = true;
     if (!(fabs(dir) >= 1e-20)) dir = copysign(1e-20, dir);  // parallel: a huge finite slope, no inf * 0
-    double inv = 1.0 / dir;
+    double inv = (double)__builtin_amdgcn_rcpf((float)dir);
     double oinv = o[a] * inv;
-    double err = fabs(oinv) * 2.4e-7 + 1e-30;
-    b.inv[a] = (float)inv;
-    b.c_near[a] = __double2float_ru(oinv + err);
-    b.c_far[a] = __double2float_rd(oinv - err);
-    bool neg = inv < 0.0;
-    b.off_near[a] = (neg ? 48u : 0u) + 16u * a;
-    b.off_far[a] = (neg ? 0u : 48u) + 16u * a;
+    double slack = fabs(oinv) * 2.4e-7 + 1e-30;
+    const double lo_s = 1.0 - 9.6e-7, hi_s = 1.0 + 9.6e-7;
+    b.inv_n[a] = (float)(inv * lo_s);
+    b.inv_f[a] = (float)(inv * hi_s);
+    b.c_n[a] = __double2float_ru(oinv * lo_s + slack);
+    b.c_f[a] = __double2float_rd(oinv * hi_s - slack);
+    b.off_near[a] = 32u * a + (inv < 0.0 ? 16u : 0u);
   }
   return b;
 }
@@ -423,8 +437,8 @@ DEV RayBox make_raybox(const Ray& r) {
 struct F4 {
   float v[4];
 };
-DEV F4 load_f4(const char* p) {
-  float4 q = *reinterpret_cast<const float4*>(p);
+DEV F4 load_f4(const char* base, uint32_t off) {
+  float4 q = *reinterpret_cast<const float4*>(base + off);
   return F4{{q.x, q.y, q.z, q.w}};
 }
 
@@ -451,44 +465,47 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     test_quad(S, S.unbounded[i], ray, Q, true);
   }
   if (S.root == REF_NONE || Q.done()) return;
-  const RayBox rb = make_raybox(ray);
-  const float qlo = Q.lo_f();
+  const RayBox rb = make_raybox(ray, Query::BEHIND);
   float qhi = Q.hi_f();
+  const char* nodes = reinterpret_cast<const char*>(S.nodes);
   st.clear();
   uint32_t cur = S.root;
   while (cur != REF_NONE) {
     while ((cur >> 30) == KIND_INNER) {
-      const char* nd = reinterpret_cast<const char*>(S.nodes + (cur & 0x3FFFFFFFu));
+      const uint32_t nd = cur << 7;  // byte offset of the node (inner kind bits are zero)
       if (COUNT) cnt.node_visits++;
-      F4 nx = load_f4(nd + rb.off_near[0]), ny = load_f4(nd + rb.off_near[1]), nz = load_f4(nd + rb.off_near[2]);
-      F4 fx = load_f4(nd + rb.off_far[0]), fy = load_f4(nd + rb.off_far[1]), fz = load_f4(nd + rb.off_far[2]);
-      uint4 ch = *reinterpret_cast<const uint4*>(nd + 96);
+      F4 nx = load_f4(nodes, nd + rb.off_near[0]), ny = load_f4(nodes, nd + rb.off_near[1]),
+         nz = load_f4(nodes, nd + rb.off_near[2]);
+      F4 fx = load_f4(nodes, nd + (rb.off_near[0] ^ 16u)), fy = load_f4(nodes, nd + (rb.off_near[1] ^ 16u)),
+         fz = load_f4(nodes, nd + (rb.off_near[2] ^ 16u));
+      uint4 ch = *reinterpret_cast<const uint4*>(nodes + nd + 96u);
       uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
       float tn[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        float tnear = fmaxf(fmaxf(fmaf(nx.v[k], rb.inv[0], -rb.c_near[0]), fmaf(ny.v[k], rb.inv[1], -rb.c_near[1])),
-                            fmaf(nz.v[k], rb.inv[2], -rb.c_near[2]));
-        float tfar = fminf(fminf(fmaf(fx.v[k], rb.inv[0], -rb.c_far[0]), fmaf(fy.v[k], rb.inv[1], -rb.c_far[1])),
-                           fmaf(fz.v[k], rb.inv[2], -rb.c_far[2]));
-        tnear = fmaf(-fabsf(tnear), BOX_REL, tnear);
-        tfar = fmaf(fabsf(tfar), BOX_REL, tfar);
-        bool hit = fmaxf(tnear, qlo) <= fminf(tfar, qhi);
+        float tnear = fmaxf(fmaxf(fmaf(nx.v[k], rb.inv_n[0], -rb.c_n[0]), fmaf(ny.v[k], rb.inv_n[1], -rb.c_n[1])),
+                            fmaf(nz.v[k], rb.inv_n[2], -rb.c_n[2]));
+        float tfar = fminf(fminf(fmaf(fx.v[k], rb.inv_f[0], -rb.c_f[0]), fmaf(fy.v[k], rb.inv_f[1], -rb.c_f[1])),
+                           fmaf(fz.v[k], rb.inv_f[2], -rb.c_f[2]));
+        bool hit = fmaxf(tnear, 0.0f) <= fminf(tfar, qhi);
         tn[k] = hit ? tnear : INFINITY;
         if (!hit) c[k] = REF_NONE;
       }
-      // order the four (distance, child) pairs, nearest first; misses carry +inf and REF_NONE
-#define RT_CSWAP(i, j)                        \
-  if (tn[j] < tn[i]) {                        \
-    float tt = tn[i]; tn[i] = tn[j]; tn[j] = tt; \
-    uint32_t cc = c[i]; c[i] = c[j]; c[j] = cc; \
-  }
-      RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
-#undef RT_CSWAP
-      if (c[3] != REF_NONE) st.push(c[3]);
-      if (c[2] != REF_NONE) st.push(c[2]);
-      if (c[1] != REF_NONE) st.push(c[1]);
-      cur = c[0] != REF_NONE ? c[0] : st.pop_or_none();
+      // nearest hit child stays in a register, the other hit children go on the stack
+      bool lt = tn[1] < tn[0];
+      float best = lt ? tn[1] : tn[0];
+      uint32_t bc = lt ? c[1] : c[0], o1 = lt ? c[0] : c[1];
+      lt = tn[2] < best;
+      best = lt ? tn[2] : best;
+      uint32_t o2 = lt ? bc : c[2];
+      bc = lt ? c[2] : bc;
+      lt = tn[3] < best;
+      uint32_t o3 = lt ? bc : c[3];
+      bc = lt ? c[3] : bc;
+      st.push_if(o1, o1 != REF_NONE);
+      st.push_if(o2, o2 != REF_NONE);
+      st.push_if(o3, o3 != REF_NONE);
+      cur = bc != REF_NONE ? bc : st.pop_or_none();
     }
     if (cur == REF_NONE) break;
     const uint32_t kind = cur >> 30;
@@ -563,7 +580,7 @@ struct ImageOut {
 constexpr int TILE = 32;  // multi-GPU partition granule, pixels per side
 constexpr int TILE_PIXELS = TILE * TILE;
 #ifndef RT_BLOCK
-#define RT_BLOCK 256
+#define RT_BLOCK 64
 #endif
 constexpr int BLOCK = RT_BLOCK;  // threads per workgroup of every kernel
 
@@ -712,6 +729,24 @@ DEV uint32_t wave_append(uint32_t* counter, bool mine) {
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// reflect_dot_eye.powf(shininess) (src/light.rs:168).  A whole-number exponent up to 1024 (the
+// default material's is 200) is raised by repeated squaring: about ten multiplications, each
+// correctly rounded, so the result stays within a few ulps of the libm value; anything else goes
+// through pow().
+DEV double specular_power(double x, double shininess) {
+  if (shininess >= 0.0 && shininess <= 1024.0 && shininess == floor(shininess)) {
+    uint32_t n = (uint32_t)shininess;
+    double result = 1.0, base = x;
+    while (n) {
+      if (n & 1u) result *= base;
+      base *= base;
+      n >>= 1;
+    }
+    return result;
+  }
+  return pow(x, shininess);
+}
+
 // Canvas::save quantisation (src/canvas.rs:60-62): ceil(clamp(c * 255, 0, 255)); NaN -> 0
 DEV uint8_t quantise(double c) {
   double v = c * 255.0;
@@ -739,8 +774,11 @@ DEV void write_pixel(const ImageOut& img, size_t p, double r, double g, double b
 //   -> surface colour.
 // MODE 0: camera rays of a scene that never spawns rays: the pixel is final, written straight
 //         to the image.  MODE 1: camera rays with ray records.  MODE 2: rays read from g.
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4
+#endif
 template <int STACK, bool COUNT, int MODE>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, RT_MIN_WAVES)
     k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_capacity, int remaining,
                  uint32_t* next_count, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
                  uint32_t tiles_x, ImageOut img) {
@@ -813,7 +851,7 @@ __global__ void __launch_bounds__(BLOCK)
       V3 rv = reflect(-lightv, normalv);
       double reflect_dot_eye = dot(rv, eyev);
       if (!(reflect_dot_eye <= 0.0)) {
-        double factor = pow(reflect_dot_eye, m.shininess);
+        double factor = specular_power(reflect_dot_eye, m.shininess);
         sr = S.light_intensity[0] * m.specular * factor;
         sg = S.light_intensity[1] * m.specular * factor;
         sb = S.light_intensity[2] * m.specular * factor;
@@ -1367,7 +1405,8 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     bool tri = L.type == RT_TRIANGLE || L.type == RT_SMOOTH_TRIANGLE;
     if (tri && (L.tri < 0 || L.tri >= d->n_triangles)) return fail(RT_ERR_INVALID, "leaf triangle out of range");
   }
-  if ((uint64_t)d->n_triangles > MAX_RUN_FIRST) return fail(RT_ERR_UNSUPPORTED, "too many triangles");
+  if ((uint64_t)d->n_triangles > MAX_RUN_FIRST || (uint64_t)d->n_leaves > (1u << 24))
+    return fail(RT_ERR_UNSUPPORTED, "too many primitives");  // node byte offsets are 32-bit
 
   HIP_TRY(hipSetDevice(device));
   s->device = device;
@@ -1398,7 +1437,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   b.leaf_items(b.top_leaves, items);
   double lo[3], hi[3];
   uint32_t root = b.bvh.build(items, lo, hi);
-  s->stack_need = b.bvh.stack_need + 2;
+  s->stack_need = b.bvh.stack_need + 2 + 3;  // + root and gate hand-over, + 3 scratch slots of push_if
   if (s->stack_need > TRAVERSAL_STACK)
     return fail(RT_ERR_UNSUPPORTED, "scene hierarchy is deeper than the traversal stack");
   if (getenv("RT_AMD_DEBUG")) {

@@ -28,11 +28,12 @@ inline uint32_t make_run(uint32_t kind, uint32_t first, uint32_t count) {
 
 // 4-wide BVH node: the world-space boxes of up to four children as f32, rounded outward from the
 // f64 boxes (a box test only has to be conservative; the primitives behind it are tested in f64).
-// Plane k of axis a of child c sits at plane[k][a][c], so a ray picks its near / far planes by
-// byte offset (0 or 48) and loads four children per 16-byte load.  Empty slots hold an inverted
-// box (+inf, -inf) and REF_NONE.
+// plane[a][k][c] is the lower (k = 0) or upper (k = 1) plane of axis a of child c: a ray picks the
+// near plane of an axis by byte offset (32 a + 0 or 16), the far plane is that offset ^ 16, and one
+// 16-byte load brings the plane of all four children.  Empty slots hold an inverted box
+// (+inf, -inf) and REF_NONE.
 struct alignas(128) BvhNode {
-  float plane[2][3][4];  // [0] = lower planes, [1] = upper planes
+  float plane[3][2][4];
   uint32_t child[4];
   uint32_t pad[4];
 };
