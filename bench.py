@@ -25,7 +25,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
-TILE = 32
 FP64_VALU_PEAK = 78.6e12  # MI355X vector FP64, FLOP/s (datasheet)
 HBM_PEAK = 8.0e12         # bytes/s (datasheet)
 
@@ -38,13 +37,6 @@ HBM_PEAK = 8.0e12         # bytes/s (datasheet)
 FLOPS_NODE, FLOPS_TRI, FLOPS_QUAD, FLOPS_GATE, FLOPS_HIT = 2 * 22, 46, 60 + 30, 36 + 30, 150
 BYTES_NODE, BYTES_TRI, BYTES_QUAD, BYTES_GATE, BYTES_HIT = 128, 80, 128, 160, 200
 BYTES_PIXEL = 3
-
-
-def part_pixel_index(width, height, part, n_parts, device):
-    """Linear pixel indices of the tiles that belong to `part` ((tx + ty) % n_parts == part)."""
-    ys, xs = torch.meshgrid(torch.arange(height, device=device), torch.arange(width, device=device), indexing="ij")
-    owner = ((xs // TILE) + (ys // TILE)) % n_parts
-    return (ys * width + xs)[owner == part].reshape(-1)
 
 
 def kernel_work(st):
@@ -97,27 +89,16 @@ def main():
     host_frames = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)] if rank == 0 else None
     copy_stream = torch.cuda.Stream(device=device)
     copy_done = [torch.cuda.Event() for _ in range(2)]
-    if world > 1:
-        idx = [part_pixel_index(W, H, p, world, device) for p in range(world)]
-        n_max = max(int(i.numel()) for i in idx)
-        mine = torch.zeros((n_max, 3), dtype=torch.uint8, device=device)
-        gathered = [torch.zeros((n_max, 3), dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+    gather = pkg.tiles.FrameGather(W, H, 3, torch.uint8, device, rank, world)
     step_no = [0]
 
     def step():
         k = step_no[0] % 2
         step_no[0] += 1
         frame = frames[k]
-        flat = frame.view(-1, 3)
         copy_done[k].synchronize()  # the copy issued two frames ago has left this buffer
         st = scene.render_device(rgb8_ptr=frame.data_ptr(), part=rank, n_parts=world)  # returns when rendered
-        if world > 1:
-            n = idx[rank].numel()
-            mine[:n] = flat[idx[rank]]
-            dist.gather(mine, gathered, dst=0)
-            if rank == 0:
-                for p in range(1, world):
-                    flat[idx[p]] = gathered[p][: idx[p].numel()]
+        gather(frame)  # RCCL gather of the other ranks' tiles into rank 0's frame
         if rank == 0:
             copy_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(copy_stream):
@@ -134,12 +115,13 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    kernel_ms = 0.0
+    kernel_ms = render_ms = 0.0
     kernel_n = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st = step()
         kernel_ms += st.kernel_ms
+        render_ms += st.render_ms
         kernel_n += st.kernel_launches
     sync()
     elapsed = time.perf_counter() - t0
@@ -228,6 +210,8 @@ def main():
         },
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
+        "breakdown_ms": {"frame": elapsed / args.steps * 1e3, "rt_render_call": render_ms / args.steps,
+                         "generation_kernels": kernel_ms / args.steps},
         "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": foot["build_seconds"], "scene_bytes": foot["scene_bytes"]},
     }
     print(json.dumps(out))

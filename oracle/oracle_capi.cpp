@@ -96,6 +96,25 @@ int orc_color_at(void* h, uint64_t n, const double* rays6, int remaining, double
   return 0;
 }
 
+// Debugging aid: every World::color_at call that hit something while tracing one ray, in call order.
+// Each record is 14 doubles: ray (6), remaining, leaf, t, n1, n2, returned colour (3).  Returns the count.
+uint64_t orc_trace(void* h, const double* ray6, int remaining, double* out14, uint64_t max_records) {
+  Scene* s = (Scene*)h;
+  std::vector<TraceRecord> trace;
+  RayCounts rc;
+  rc.trace = &trace;
+  s->world.color_at(ray_new(point(ray6[0], ray6[1], ray6[2]), vector(ray6[3], ray6[4], ray6[5])), remaining, &rc);
+  uint64_t n = std::min<uint64_t>(trace.size(), max_records);
+  for (uint64_t i = 0; i < n; i++) {
+    const TraceRecord& t = trace[i];
+    double* o = out14 + i * 14;
+    for (int k = 0; k < 6; k++) o[k] = t.ray[k];
+    o[6] = t.remaining; o[7] = t.leaf; o[8] = t.t; o[9] = t.n1; o[10] = t.n2;
+    o[11] = t.color[0]; o[12] = t.color[1]; o[13] = t.color[2];
+  }
+  return n;
+}
+
 // World::intersect followed by Intersections::hit: t (NaN when none) and leaf id (-1 when none).
 int orc_intersect_hit(void* h, uint64_t n, const double* rays6, double* t_out, int32_t* leaf_out) {
   Scene* s = (Scene*)h;

@@ -1037,6 +1037,15 @@ Color World::color_at(const Ray& r, int remaining, RayCounts* rc, int* hit_leaf)
   }
   if (hit_leaf) *hit_leaf = h.what->leaf_id;
   Computation comps = computation_new(r, h, &xs);
+  if (rc && rc->trace) {
+    size_t slot = rc->trace->size();
+    rc->trace->push_back(TraceRecord{{r.origin.x, r.origin.y, r.origin.z, r.direction.x, r.direction.y, r.direction.z},
+                                     remaining, h.what->leaf_id, h.t, comps.n1, comps.n2, {0, 0, 0}});
+    Color c = shade_hit(comps, remaining, rc);
+    TraceRecord& rec = (*rc->trace)[slot];
+    rec.color[0] = c.r; rec.color[1] = c.g; rec.color[2] = c.b;
+    return c;
+  }
   return shade_hit(comps, remaining, rc);
 }
 

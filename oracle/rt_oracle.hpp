@@ -220,8 +220,17 @@ double schlick(const Computation& c);
 bool intersection_allowed(ShapeType op, bool which_hit, bool inl, bool inr);
 
 // ---------------------------------------------------------------- world.rs
+// One record per World::color_at call when tracing (debugging aid of the tests): the ray, what it
+// hit, the refraction indices and the colour the call returned.
+struct TraceRecord {
+  double ray[6];
+  int remaining, leaf;
+  double t, n1, n2;
+  double color[3];
+};
 struct RayCounts {
   uint64_t primary = 0, shadow = 0, reflect = 0, refract = 0;
+  std::vector<TraceRecord>* trace = nullptr;
 };
 struct World {
   std::vector<Shape> objects;

@@ -124,8 +124,11 @@ DEV void check_cube_axis(double origin, double direction, double& tmin, double& 
 
 // Intersections of an object-space ray with one quadric-type primitive, in the
 // reference's emission order.  Returns their count (at most 4).
-DEV int intersect_quadric(int type, int closed, double minimum, double maximum, const Ray& r, double t[4]) {
+// type may carry QUAD_SKIP_PARALLEL / QUAD_ONLY_PARALLEL (cones only): the two copies of a bounded
+// cone split its rays by the reference's own |a| < FEQ_EPSILON branch, so each ray meets one of them.
+DEV int intersect_quadric(int type_flags, int closed, double minimum, double maximum, const Ray& r, double t[4]) {
   int n = 0;
+  const int type = type_flags & QUAD_TYPE_MASK;
   if (type == RT_SPHERE) {  // 839-866
     double a = dot(r.d, r.d);
     double b = 2.0 * dot(r.d, r.o);
@@ -172,7 +175,10 @@ DEV int intersect_quadric(int type, int closed, double minimum, double maximum, 
     if (!cone) {
       if (a < FEQ_EPSILON) walls = false;  // 990-994: caps only
     } else if (fabs(a) < FEQ_EPSILON) {    // 1089-1103: caps first, then the single root
+      if (type_flags & QUAD_SKIP_PARALLEL) return 0;
       walls = false;
+    } else if (type_flags & QUAD_ONLY_PARALLEL) {
+      return 0;
     }
     if (walls) {
       double disc = b * b - 4.0 * a * c;
@@ -463,6 +469,19 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
   for (int i = 0; i < S.n_unbounded; i++) {
     if (COUNT) cnt.quad_tests++;
     test_quad(S, S.unbounded[i], ray, Q, true);
+  }
+  if (S.n_bands > 0) {
+    const double xx = ray.d.x * ray.d.x, yy = ray.d.y * ray.d.y, zz = ray.d.z * ray.d.z;
+    const double xy = ray.d.x * ray.d.y, xz = ray.d.x * ray.d.z, yz = ray.d.y * ray.d.z;
+    const double dd = xx + yy + zz;
+    for (int i = 0; i < S.n_bands; i++) {
+      const ConeBand& cb = S.bands[i];
+      double a = fma(cb.q[0], xx, fma(cb.q[1], yy, fma(cb.q[2], zz, fma(cb.q[3], xy, fma(cb.q[4], xz, cb.q[5] * yz)))));
+      if (fabs(a) < FEQ_EPSILON * (1.0 + 1e-6) + cb.slack * dd) {
+        if (COUNT) cnt.quad_tests++;
+        test_quad(S, S.band_prims[cb.prim], ray, Q, true);
+      }
+    }
   }
   if (S.root == REF_NONE || Q.done()) return;
   const RayBox rb = make_raybox(ray, Query::BEHIND);
@@ -1240,7 +1259,8 @@ struct SceneBuild {
   std::vector<std::vector<int>> gate_children, gate_leaves;
   std::vector<int> top_gates, top_leaves;
   std::vector<Gate> gates;
-  std::vector<QuadPrim> quad_src, unbounded;
+  std::vector<QuadPrim> quad_src, unbounded, band_prims;
+  std::vector<ConeBand> bands;
   std::vector<TriIsect> tri_src;
   std::vector<int> tri_xform;  // device xform index or -1 (identity)
   int stack_need = 1;
@@ -1286,7 +1306,31 @@ struct SceneBuild {
       } else {
         it.kind = KIND_QUAD;
         it.index = (uint32_t)quad_src.size();
-        quad_src.push_back(make_quad(li));
+        QuadPrim q = make_quad(li);
+        if (L.type == RT_CONE) {
+          // a(d) = |M d|^2 under diag(1, -1, 1), M = the linear part of world -> object
+          const double* m = q.m;
+          const double sg[3] = {1.0, -1.0, 1.0};
+          double Q[3][3], sum = 0.0;
+          for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+              Q[i][j] = 0.0;
+              for (int r = 0; r < 3; r++) Q[i][j] += sg[r] * m[r * 4 + i] * m[r * 4 + j];
+            }
+          ConeBand cb{};
+          cb.q[0] = Q[0][0]; cb.q[1] = Q[1][1]; cb.q[2] = Q[2][2];
+          cb.q[3] = 2.0 * Q[0][1]; cb.q[4] = 2.0 * Q[0][2]; cb.q[5] = 2.0 * Q[1][2];
+          for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) sum += m[r * 4 + c] * m[r * 4 + c];
+          cb.slack = 1e-11 * sum;
+          cb.prim = (uint32_t)band_prims.size();
+          bands.push_back(cb);
+          QuadPrim only = q;
+          only.type |= QUAD_ONLY_PARALLEL;
+          band_prims.push_back(only);
+          q.type |= QUAD_SKIP_PARALLEL;
+        }
+        quad_src.push_back(q);
       }
       items.push_back(it);
     }
@@ -1444,8 +1488,8 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     int occ = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_generation<STACK_SMALL, false, 0>, BLOCK, 0);
     fprintf(stderr, "[rt_amd] k_generation<%d> blocks of %d per CU (occupancy API): %d\n", STACK_SMALL, BLOCK, occ);
-    fprintf(stderr, "[rt_amd] leaves=%d gates=%d nodes=%zu tris=%zu quads=%zu unbounded=%zu stack_need=%d\n", d->n_leaves,
-            d->n_gates, b.bvh.nodes.size(), b.bvh.tri_order.size(), b.bvh.quad_order.size(), b.unbounded.size(),
+    fprintf(stderr, "[rt_amd] leaves=%d gates=%d nodes=%zu tris=%zu quads=%zu unbounded=%zu bands=%zu stack_need=%d\n", d->n_leaves,
+            d->n_gates, b.bvh.nodes.size(), b.bvh.tri_order.size(), b.bvh.quad_order.size(), b.unbounded.size(), b.bands.size(),
             s->stack_need);
   }
 
@@ -1514,6 +1558,9 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((rc = upload(s, quads, &s->dev.quads))) return rc;
   if ((rc = upload(s, b.gates, &s->dev.gates))) return rc;
   if ((rc = upload(s, b.unbounded, &s->dev.unbounded))) return rc;
+  if ((rc = upload(s, b.bands, &s->dev.bands))) return rc;
+  if ((rc = upload(s, b.band_prims, &s->dev.band_prims))) return rc;
+  s->dev.n_bands = (int32_t)b.bands.size();
   if ((rc = upload(s, leaves, &s->dev.leaves))) return rc;
   if ((rc = upload(s, xforms, &s->dev.xforms))) return rc;
   if ((rc = upload(s, tri_shade, &s->dev.tri_shade))) return rc;

@@ -55,6 +55,23 @@ struct alignas(128) QuadPrim {
 };
 static_assert(sizeof(QuadPrim) == 128, "QuadPrim must be one cache line");
 
+// A cone treats a ray whose object-space direction satisfies |dx^2 - dy^2 + dz^2| < FEQ_EPSILON as
+// parallel to one of its halves and then reports the single root -c / 2b without the y-range check
+// (reference src/shape.rs:1089-1103): that hit can lie anywhere on the infinite cone, outside any
+// box.  A bounded cone is therefore stored twice: in the BVH with QUAD_SKIP_PARALLEL (every other
+// ray), and in the band list with QUAD_ONLY_PARALLEL, which every ray scans by direction only.
+constexpr int32_t QUAD_TYPE_MASK = 0xFF, QUAD_SKIP_PARALLEL = 0x100, QUAD_ONLY_PARALLEL = 0x200;
+
+// Direction pre-filter of one band-list cone: a(d) = q . (dx^2, dy^2, dz^2, dx dy, dx dz, dy dz) is the
+// cone's quadratic coefficient for a world-space direction d, up to rounding covered by slack |d|^2.
+struct alignas(64) ConeBand {
+  double q[6];
+  double slack;
+  uint32_t prim;  // index into band_prims
+  uint32_t pad;
+};
+static_assert(sizeof(ConeBand) == 64, "ConeBand layout");
+
 // One reference Group: exact bounding-box gate in group space, then its subtree.
 struct alignas(32) Gate {
   uint32_t root;  // traversal reference of the subtree (REF_NONE when empty)
@@ -109,6 +126,8 @@ struct SceneDev {
   const QuadPrim* quads;
   const Gate* gates;
   const QuadPrim* unbounded;  // tested for every ray (planes, infinite cylinders, very large shapes)
+  const ConeBand* bands;      // bounded cones: direction pre-filter of their parallel-ray branch
+  const QuadPrim* band_prims;
   const LeafShade* leaves;
   const XformDev* xforms;
   const TriShade* tri_shade;
@@ -117,7 +136,7 @@ struct SceneDev {
   uint32_t root;
   int32_t n_unbounded;
   int32_t n_leaves;
-  int32_t pad;
+  int32_t n_bands;
   double light_intensity[3];
   double light_position[3];
 };

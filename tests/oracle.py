@@ -30,6 +30,8 @@ def lib():
         L.orc_render.argtypes = [vp, C.c_int, u64, u64, u64, u64, vp, vp, vp, C.c_char_p, C.c_int]
         L.orc_color_at.argtypes = [vp, u64, vp, C.c_int, vp, vp, vp]
         L.orc_intersect_hit.argtypes = [vp, u64, vp, vp, vp]
+        L.orc_trace.argtypes = [vp, vp, C.c_int, vp, u64]
+        L.orc_trace.restype = u64
         L.orc_is_shadowed.argtypes = [vp, u64, vp, vp]
         L.orc_ray_for_pixel.argtypes = [vp, u64, vp, vp]
         L.orc_quantise.argtypes = [u64, vp, vp]
@@ -113,6 +115,14 @@ class OracleScene:
         counts = (C.c_uint64 * 4)()
         lib().orc_color_at(self._h, len(rays), _p(rays), remaining, _p(rgb), _p(leaf), counts)
         return rgb, leaf, [int(c) for c in counts]
+
+    def trace(self, ray, remaining=5):
+        """Every color_at call one ray causes that hit something: rows of
+        ray(6), remaining, leaf, t, n1, n2, colour(3) in call order."""
+        ray = np.ascontiguousarray(ray, np.float64).reshape(6)
+        out = np.zeros((256, 14), np.float64)
+        n = lib().orc_trace(self._h, _p(ray), remaining, _p(out), len(out))
+        return out[:n]
 
     def intersect_hit(self, rays):
         rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)

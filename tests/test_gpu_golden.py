@@ -1,0 +1,65 @@
+"""GPU results against the committed golden fixtures (tests/golden/, written by make_golden.py from the oracle)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+F64_TOL = 1e-9  # f64 colours: same operations in the same order; only pow / libm differ in the last bits
+
+
+def check(out, stats, g, n_pix):
+    assert np.array_equal(out["hit_leaf"] >= 0, g["hit_leaf"] >= 0)  # hit / miss mask: bit exact
+    assert (out["hit_leaf"] != g["hit_leaf"]).sum() <= n_pix * 1e-3
+    assert np.abs(out["rgb64"] - g["rgb64"]).max() <= F64_TOL
+    d8 = np.abs(out["rgb8"].astype(int) - orc.quantise(g["rgb64"]).astype(int)).max(axis=2)
+    assert (d8 > 1).sum() == 0 and (d8 == 1).sum() <= n_pix * 1e-3
+    assert [stats.primary, stats.shadow, stats.reflect, stats.refract] == [int(c) for c in g["counts"]]
+
+
+@pytest.mark.parametrize("name", ["example", "egg", "glass", "pattern", "teapot"])
+def test_shipped_scene_against_golden(pkg, name):
+    g = np.load(os.path.join(GOLDEN, "scene_%s.npz" % name))
+    s = pkg.Scene.from_file(os.path.join(ROOT, "scenes", name + ".json"), base_dir=ROOT, device=0)
+    w, h = int(g["size"][0]), int(g["size"][1])
+    s.set_canvas(w, h)
+    out, st = s.render()
+    check(out, st, g, w * h)
+
+
+def test_every_primitive_pattern_and_group_against_golden(pkg):
+    g = np.load(os.path.join(GOLDEN, "allprims.npz"))
+    with open(os.path.join(GOLDEN, "allprims.json")) as f:
+        s = pkg.Scene(f.read(), ROOT, device=0)
+    out, st = s.render()
+    check(out, st, g, out["hit_leaf"].size)
+    rgb, leaf, st2 = s.color_at(g["rays"])
+    assert np.array_equal(leaf, g["ray_leaf"])
+    assert np.abs(rgb - g["ray_rgb"]).max() <= F64_TOL
+    assert [st2.primary, st2.shadow, st2.reflect, st2.refract] == [int(c) for c in g["ray_counts"]]
+    t, leaf2 = s.intersect_hit(g["rays"])
+    assert np.array_equal(leaf2, g["ray_leaf"])
+    hit = leaf2 >= 0
+    assert np.isnan(t[~hit]).all()
+    # identical object-space arithmetic for top-level shapes: the distance itself is bit exact
+    assert np.array_equal(t[hit], g["ray_t"][hit])
+
+
+def test_remaining_limits_the_generations(pkg):
+    g = np.load(os.path.join(GOLDEN, "allprims.npz"))
+    with open(os.path.join(GOLDEN, "allprims.json")) as f:
+        text = f.read()
+    s = pkg.Scene(text, ROOT, device=0)
+    ref = orc.OracleScene(text, ROOT)
+    rays = g["rays"][:200]
+    for remaining in (0, 1, 3):
+        rgb, leaf, st = s.color_at(rays, remaining=remaining)
+        want, wleaf, counts = ref.color_at(rays, remaining=remaining)
+        assert np.array_equal(leaf, wleaf)
+        assert np.abs(rgb - want).max() <= F64_TOL
+        assert [st.primary, st.shadow, st.reflect, st.refract] == counts
+        assert st.generations <= remaining + 1

@@ -1,0 +1,99 @@
+"""CPU tests of the host side and of the C ABI surface (no GPU, no compute calls)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    amd, host = pkg.libraries()
+    header = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    names = set(re.findall(r"\b(rt_[a-z_]+)\s*\(", header))
+    assert {"rt_scene_create", "rt_render", "rt_color_at", "rt_last_error"} <= names
+    for n in sorted(names):
+        assert hasattr(amd, n), "librt_amd.so does not export %s" % n
+    for n in ("rth_scene_from_json", "rth_parallel_render", "rth_ppm_encode", "rth_scene_camera"):
+        assert hasattr(host, n)
+
+
+def test_struct_layouts_match_the_header(pkg):
+    assert ctypes.sizeof(pkg.RtCamera) == 8 + 3 * 8 + 16 * 8
+    assert ctypes.sizeof(pkg.RtStats) == 4 * 8 + 2 * 8 + 2 * 8 + 8 * 8
+
+
+@pytest.mark.parametrize("name", ["example", "egg", "glass", "pattern", "teapot"])
+def test_flattening_agrees_with_the_oracle_tree(pkg, name):
+    path = os.path.join(ROOT, "scenes", name + ".json")
+    s = pkg.Scene.from_file(path, base_dir=ROOT, device=None)
+    o = orc.OracleScene.from_file(path, base_dir=ROOT)
+    info = s.info()
+    assert (info["width"], info["height"]) == (o.info()["width"], o.info()["height"])
+    assert info["leaves"] == o.info()["leaves"]  # same depth-first numbering of non-container shapes
+
+
+def test_camera_description(pkg):
+    s = pkg.Scene.from_file(os.path.join(ROOT, "scenes", "example.json"), base_dir=ROOT, device=None)
+    s.set_canvas(201, 101)
+    cam = s.camera()
+    half_view = np.tan(1.0472 / 2.0)
+    assert cam.hsize == 201 and cam.vsize == 101
+    assert cam.half_width == half_view and cam.half_height == half_view / (201 / 101)
+    assert cam.pixel_size == half_view * 2.0 / 201
+    # the camera sits at camera_from: last column of the inverse view transform
+    assert [cam.inv[3], cam.inv[7], cam.inv[11]] == pytest.approx([0.0, 1.5, -10.0], abs=1e-12)
+    assert list(cam.inv[12:16]) == pytest.approx([0, 0, 0, 1], abs=1e-12)
+
+
+def test_ppm_bytes_match_canvas_save(pkg):
+    rng = np.random.default_rng(5)
+    rgb = rng.uniform(-0.2, 1.3, (7, 23, 3))
+    rgb[0, 0] = [0.0, 1.0, 1e-9]
+    want = orc.ppm_encode(rgb)
+    got = pkg.ppm_encode(orc.quantise(rgb))
+    assert got == want
+    assert got.startswith(b"P3\n23 7\n255\n") and got.endswith(b"\n")
+
+
+def test_loader_errors_keep_the_reference_messages(pkg):
+    base = json.load(open(os.path.join(ROOT, "scenes", "example.json")))
+
+    def load(**kw):
+        return pkg.Scene(json.dumps(dict(base, **kw)), ROOT, device=None)
+
+    with pytest.raises(pkg.RtError, match="Unrecognized shape type"):
+        load(shapes=[{"ty": "torus"}])
+    with pytest.raises(pkg.RtError, match="Shape transform should have an inverse"):
+        load(shapes=[{"ty": "sphere", "transform": [1, 0, 0, 0]}])
+    with pytest.raises(pkg.RtError, match="Unrecognized pattern"):
+        load(shapes=[{"ty": "sphere", "material": {"color": [1, 1, 1], "pattern": {"ty": "blend"}}}])
+    with pytest.raises(pkg.RtError, match="Model requires a path"):
+        load(shapes=[{"ty": "model"}])
+    with pytest.raises(pkg.RtError, match="Failed to open file"):
+        load(shapes=[{"ty": "model", "path": "models/absent.obj"}])
+    with pytest.raises(pkg.RtError, match="missing field"):
+        pkg.Scene('{"canvas_width": 10}', ROOT, device=None)
+    with pytest.raises(pkg.RtError) as e:
+        load(shapes=[{"ty": "union", "children": [{"ty": "sphere"}, {"ty": "cube"}]}])
+    assert e.value.status == -2  # CSG is valid for the reference, unsupported on the device path
+
+
+def test_empty_groups_and_empty_shapes_flatten(pkg):
+    base = json.load(open(os.path.join(ROOT, "scenes", "example.json")))
+    shapes = [{"ty": "group"}, {"ty": "group", "children": [{"ty": "empty"}, {"ty": "group", "children": []}]},
+              {"ty": "sphere"}]
+    s = pkg.Scene(json.dumps(dict(base, shapes=shapes)), ROOT, device=None)
+    info = s.info()
+    assert info["leaves"] == 2 and info["gates"] == 1  # childless groups vanish (src/shape.rs:1186-1188)
+
+
+def test_rendering_without_a_device_fails_loudly(pkg):
+    s = pkg.Scene.from_file(os.path.join(ROOT, "scenes", "example.json"), base_dir=ROOT, device=None)
+    with pytest.raises(pkg.RtError):
+        s.render()

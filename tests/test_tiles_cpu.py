@@ -1,0 +1,66 @@
+"""The multi-GPU partition and framebuffer gather, exercised on CPU with two gloo ranks."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_parts_partition_the_image(pkg):
+    for (w, h, n) in [(1920, 1080, 8), (100, 70, 3), (31, 9, 2), (64, 64, 1)]:
+        seen = torch.zeros(w * h, dtype=torch.int32)
+        for p in range(n):
+            idx = pkg.tiles.part_pixel_index(w, h, p, n)
+            seen[idx] += 1
+            ys, xs = idx // w, idx % w
+            assert bool((((xs // 32) + (ys // 32)) % n == p).all())
+        assert bool((seen == 1).all())
+    sizes = [pkg.tiles.part_pixel_index(1920, 1080, p, 8).numel() for p in range(8)]
+    assert max(sizes) - min(sizes) <= 0.05 * max(sizes)  # balanced to a few percent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, w, h, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        truth = torch.stack([xs % 251, ys % 241, (xs * 7 + ys * 13) % 239], dim=-1).to(torch.uint8)
+        frame = torch.zeros((h, w, 3), dtype=torch.uint8)
+        mine = pkg.tiles.part_pixel_index(w, h, rank, world)
+        frame.view(-1, 3)[mine] = truth.view(-1, 3)[mine]  # what this rank's GPU would have rendered
+        gather = pkg.tiles.FrameGather(w, h, 3, torch.uint8, "cpu", rank, world)
+        gather(frame)
+        if rank == 0:
+            out.put(bool(torch.equal(frame, truth)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_rebuilds_the_frame():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 150, 100, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) is True
