@@ -209,6 +209,13 @@ int rt_intersect_hit(rt_scene* scene, uint64_t n, const double* rays6, double* t
 /* `World::is_shadowed` for n points (n x 3 doubles) -> n bytes.  Host buffers. */
 int rt_is_shadowed(rt_scene* scene, uint64_t n, const double* points3, uint8_t* shadowed);
 
+/* Diagnostic, host only (no GPU needed): checks the direction index that finds the cones whose
+ * parallel-ray branch (src/shape.rs:1089-1103) a ray direction triggers.  Builds the index over
+ * n_bands random cones and looks up n_dirs random directions; returns the number of cones the
+ * index failed to list for a direction that needs them (0 = conservative) or a negative rt_status.
+ * No counterpart in the reference, which scans every shape for every ray. */
+int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int* grid_n, uint64_t* entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -35,6 +36,7 @@
 #include <vector>
 
 #include "../../include/rt_amd.h"
+#include "band_grid.h"
 #include "bvh_build.h"
 #include "rt_types.h"
 
@@ -361,7 +363,7 @@ struct LdsStack {
   uint32_t* base;
   int sp;
   DEV void init(uint32_t* lds) {
-    base = lds + threadIdx.x;
+    base = lds + (BLOCK == 64 ? (uint32_t)__lane_id() : threadIdx.x);
     sp = 0;
   }
   DEV void push(uint32_t r) {
@@ -474,13 +476,31 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     const double xx = ray.d.x * ray.d.x, yy = ray.d.y * ray.d.y, zz = ray.d.z * ray.d.z;
     const double xy = ray.d.x * ray.d.y, xz = ray.d.x * ray.d.z, yz = ray.d.y * ray.d.z;
     const double dd = xx + yy + zz;
-    for (int i = 0; i < S.n_bands; i++) {
-      const ConeBand& cb = S.bands[i];
+    auto band = [&](const ConeBand& cb) {
       double a = fma(cb.q[0], xx, fma(cb.q[1], yy, fma(cb.q[2], zz, fma(cb.q[3], xy, fma(cb.q[4], xz, cb.q[5] * yz)))));
       if (fabs(a) < FEQ_EPSILON * (1.0 + 1e-6) + cb.slack * dd) {
         if (COUNT) cnt.quad_tests++;
         test_quad(S, S.band_prims[cb.prim], ray, Q, true);
       }
+    };
+    if (S.band_grid_n > 0 && dd >= 1.0 - 1e-6) {
+      // cell of the direction on the sign-folded cube map; the grid was built for |d| >= 1 - 1e-6
+      const int n = S.band_grid_n;
+      int m = zz > yy ? 2 : 1;
+      m = xx >= (m == 2 ? zz : yy) ? 0 : m;
+      const double dm = m == 0 ? ray.d.x : (m == 1 ? ray.d.y : ray.d.z);
+      const double da = m == 0 ? ray.d.y : (m == 1 ? ray.d.z : ray.d.x);
+      const double dc = m == 0 ? ray.d.z : (m == 1 ? ray.d.x : ray.d.y);
+      const float inv = __builtin_amdgcn_rcpf((float)dm);
+      const float half_n = 0.5f * (float)n;
+      int iu = (int)floorf(((float)da * inv + 1.0f) * half_n), iv = (int)floorf(((float)dc * inv + 1.0f) * half_n);
+      iu = iu < 0 ? 0 : (iu >= n ? n - 1 : iu);
+      iv = iv < 0 ? 0 : (iv >= n ? n - 1 : iv);
+      const uint32_t cell = ((uint32_t)m * n + iv) * n + iu;
+      const uint32_t end = S.band_start[cell + 1];
+      for (uint32_t k = S.band_start[cell]; k < end; k++) band(S.bands[S.band_items[k]]);
+    } else {
+      for (int i = 0; i < S.n_bands; i++) band(S.bands[i]);
     }
   }
   if (S.root == REF_NONE || Q.done()) return;
@@ -602,6 +622,9 @@ constexpr int TILE_PIXELS = TILE * TILE;
 #define RT_BLOCK 64
 #endif
 constexpr int BLOCK = RT_BLOCK;  // threads per workgroup of every kernel
+// Thread index within the workgroup.  With one wave per workgroup it is the lane id, which costs two
+// instructions to recompute wherever it is needed instead of occupying a register for the whole kernel.
+DEV uint32_t thread_in_block() { return BLOCK == 64 ? (uint32_t)__lane_id() : threadIdx.x; }
 
 // Device statistics block (unsigned long long): [0..3] closest-hit traversal work,
 // [4..7] shadow traversal work, then three ray counters spread over 64 slots each
@@ -651,7 +674,7 @@ DEV void flush_counters(const Counters& c, unsigned long long* out) {
   for (int k = 0; k < 4; k++) {
     unsigned long long s = v[k];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&out[k], s);
+    if ((thread_in_block() & 63) == 0 && s) atomicAdd(&out[k], s);
   }
 }
 
@@ -740,7 +763,7 @@ DEV V3 local_normal(const SceneDev& S, const LeafShade& L, V3 at, double u, doub
 // Appends `mine` items per lane to a queue: one atomic per wave, prefix by ballot.
 DEV uint32_t wave_append(uint32_t* counter, bool mine) {
   unsigned long long mask = __ballot(mine);
-  uint32_t lane = threadIdx.x & 63u;
+  uint32_t lane = thread_in_block() & 63u;
   uint32_t total = (uint32_t)__popcll(mask);
   uint32_t base = 0;
   if (lane == 0 && total) base = atomicAdd(counter, total);
@@ -775,14 +798,36 @@ DEV uint8_t quantise(double c) {
   return (v == v) ? (uint8_t)v : (uint8_t)0;
 }
 
-DEV void write_pixel(const ImageOut& img, size_t p, double r, double g, double b, int leaf) {
-  if (img.rgb64) {
-    img.rgb64[p * 3 + 0] = r; img.rgb64[p * 3 + 1] = g; img.rgb64[p * 3 + 2] = b;
+// Canvas::write_pixel for the 8x8 pixel block of a wave; all 64 lanes call it together.  The bytes
+// of one block row (8 pixels, 24 bytes) are gathered across lanes and stored as six dwords, so the
+// framebuffer leaves the chip as full dwords instead of three single-byte stores per pixel.
+DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y, bool active, double r, double g,
+                     double b, int leaf) {
+  const size_t p = (size_t)y * hsize + x;
+  if (active) {
+    if (img.rgb64) {
+      img.rgb64[p * 3 + 0] = r; img.rgb64[p * 3 + 1] = g; img.rgb64[p * 3 + 2] = b;
+    }
+    if (img.hit_leaf) img.hit_leaf[p] = leaf;
   }
-  if (img.rgb8) {
-    img.rgb8[p * 3 + 0] = quantise(r); img.rgb8[p * 3 + 1] = quantise(g); img.rgb8[p * 3 + 2] = quantise(b);
+  if (!img.rgb8) return;
+  const uint32_t v = (uint32_t)quantise(r) | ((uint32_t)quantise(g) << 8) | ((uint32_t)quantise(b) << 16);
+  const uint32_t lane = thread_in_block() & 63u, col = lane & 7u, row_base = lane & ~7u;
+  // dword `col` (0..5) of the row holds bytes 4 col .. 4 col + 3, which belong to pixels p0 and p0 + 1
+  const uint32_t p0 = (4u * col) / 3u, shift = 8u * (4u * col - 3u * p0);
+  const uint32_t lo = __shfl(v, (int)(row_base + (p0 < 7u ? p0 : 7u)));
+  const uint32_t hi = __shfl(v, (int)(row_base + (p0 + 1u < 7u ? p0 + 1u : 7u)));
+  const uint32_t x0 = x - col;
+  const bool whole_rows = (hsize & 3u) == 0u && x0 + 8u <= hsize && ((uintptr_t)img.rgb8 & 3u) == 0u;  // wave-uniform
+  if (whole_rows) {
+    if (active && col < 6u) {
+      const unsigned long long cat = (unsigned long long)lo | ((unsigned long long)hi << 24);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(img.rgb8 + ((size_t)y * hsize + x0) * 3u) + col;
+      *dst = (uint32_t)(cat >> shift);
+    }
+  } else if (active) {
+    img.rgb8[p * 3 + 0] = (uint8_t)v; img.rgb8[p * 3 + 1] = (uint8_t)(v >> 8); img.rgb8[p * 3 + 2] = (uint8_t)(v >> 16);
   }
-  if (img.hit_leaf) img.hit_leaf[p] = leaf;
 }
 
 // One generation of rays, start to finish, one ray per lane:
@@ -796,25 +841,24 @@ DEV void write_pixel(const ImageOut& img, size_t p, double r, double g, double b
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
+#ifndef RT_MIN_WAVES_SPAWN
+#define RT_MIN_WAVES_SPAWN 3
+#endif
 template <int STACK, bool COUNT, int MODE>
-__global__ void __launch_bounds__(BLOCK, RT_MIN_WAVES)
+__global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES_SPAWN)
     k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_capacity, int remaining,
                  uint32_t* next_count, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
                  uint32_t tiles_x, ImageOut img) {
   __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
   LdsStack<STACK, BLOCK> st;
   st.init(lds);
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t i = blockIdx.x * BLOCK + thread_in_block();
   bool active = i < n;
-  size_t pixel = 0;
+  uint32_t px = 0, py = 0;
   Ray ray{v3(0, 0, 0), v3(0, 0, 1)};
   if (MODE != 2) {
-    uint32_t x = 0, y = 0;
-    active = active && ray_pixel(tiles, tiles_x, cam, i, x, y);
-    if (active) {
-      ray = camera_ray(cam, x, y);
-      pixel = (size_t)y * cam.hsize + x;
-    }
+    active = active && ray_pixel(tiles, tiles_x, cam, i, px, py);
+    if (active) ray = camera_ray(cam, px, py);
   } else if (active) {
     ray = load_ray(g, i);
   }
@@ -983,15 +1027,15 @@ __global__ void __launch_bounds__(BLOCK, RT_MIN_WAVES)
     out_b = SQ.found ? ab : lb;
   }
   if (MODE == 0) {
-    if (active) write_pixel(img, pixel, out_r, out_g, out_b, leaf);
+    write_pixel(img, cam.hsize, px, py, active, out_r, out_g, out_b, leaf);
   } else if (i < n) {
     g.cr[i] = out_r; g.cg[i] = out_g; g.cb[i] = out_b;
   }
 
   // ray statistics, one add per wave and kind, spread over STAT_SLOTS addresses
   unsigned long long hm = __ballot(hit), rm = __ballot(want_reflect), fm = __ballot(want_refract);
-  if ((threadIdx.x & 63) == 0) {
-    uint32_t slot = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % STAT_SLOTS;
+  if ((thread_in_block() & 63) == 0) {
+    uint32_t slot = (blockIdx.x * (BLOCK / 64) + (thread_in_block() >> 6)) % STAT_SLOTS;
     if (hm) atomicAdd(&stats[STAT_RAYS + 0 * STAT_SLOTS + slot], (unsigned long long)__popcll(hm));
     if (rm) atomicAdd(&stats[STAT_RAYS + 1 * STAT_SLOTS + slot], (unsigned long long)__popcll(rm));
     if (fm) atomicAdd(&stats[STAT_RAYS + 2 * STAT_SLOTS + slot], (unsigned long long)__popcll(fm));
@@ -1034,10 +1078,15 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(GenView g, uint32_t n, GenVie
 __global__ void __launch_bounds__(BLOCK)
     k_output_image(GenView g, uint32_t n, CameraDev cam, const uint32_t* tiles, uint32_t tiles_x, ImageOut img) {
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
-  uint32_t x, y;
-  if (!ray_pixel(tiles, tiles_x, cam, i, x, y)) return;
-  write_pixel(img, (size_t)y * cam.hsize + x, g.cr[i], g.cg[i], g.cb[i], g.leaf[i]);
+  uint32_t x = 0, y = 0;
+  const bool active = i < n && ray_pixel(tiles, tiles_x, cam, i, x, y);
+  double r = 0.0, gg = 0.0, b = 0.0;
+  int leaf = -1;
+  if (active) {
+    r = g.cr[i]; gg = g.cg[i]; b = g.cb[i];
+    leaf = g.leaf[i];
+  }
+  write_pixel(img, cam.hsize, x, y, active, r, gg, b, leaf);
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -1561,6 +1610,14 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((rc = upload(s, b.bands, &s->dev.bands))) return rc;
   if ((rc = upload(s, b.band_prims, &s->dev.band_prims))) return rc;
   s->dev.n_bands = (int32_t)b.bands.size();
+  {
+    BandGrid grid = build_band_grid(b.bands, (size_t)1 << 29);  // at most 2 GiB of entries
+    s->dev.band_grid_n = grid.n;
+    if ((rc = upload(s, grid.start, &s->dev.band_start))) return rc;
+    if ((rc = upload(s, grid.items, &s->dev.band_items))) return rc;
+    if (getenv("RT_AMD_DEBUG"))
+      fprintf(stderr, "[rt_amd] band grid n=%d cells=%zu entries=%zu\n", grid.n, grid.start.size(), grid.items.size());
+  }
   if ((rc = upload(s, leaves, &s->dev.leaves))) return rc;
   if ((rc = upload(s, xforms, &s->dev.xforms))) return rc;
   if ((rc = upload(s, tri_shade, &s->dev.tri_shade))) return rc;
@@ -1603,6 +1660,93 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   }
   *out = s;
   return RT_OK;
+}
+
+// Host-only self-check of the cone direction index: n_bands random cone bands, n_dirs random unit
+// directions (half of them placed inside a band); returns how many (direction, band) pairs that pass
+// the band pre-filter are missing from the direction's grid cell (0 when the index is conservative),
+// or a negative rt_status.  *grid_n receives the grid resolution, *entries its size.
+extern "C" int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int* grid_n, uint64_t* entries) {
+  if (n_bands < 0 || n_dirs < 0) return fail(RT_ERR_INVALID, "negative count");
+  uint64_t state = seed;
+  auto next = [&]() {  // splitmix64
+    uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  auto uni = [&](double lo, double hi) { return lo + (hi - lo) * ((next() >> 11) * (1.0 / 9007199254740992.0)); };
+  std::vector<ConeBand> bands(n_bands);
+  std::vector<std::array<double, 9>> mats(n_bands);
+  for (int i = 0; i < n_bands; i++) {
+    // rows of a random rotation (from a random quaternion) divided by random scales: world -> object
+    double qv[4], nq = 0;
+    for (double& v : qv) { v = uni(-1, 1); nq += v * v; }
+    nq = sqrt(nq);
+    double w = qv[0] / nq, x = qv[1] / nq, y = qv[2] / nq, z = qv[3] / nq;
+    double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                   2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    double sc[3] = {uni(0.2, 1.0), uni(0.2, 1.0), uni(0.2, 1.0)};
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) mats[i][r * 3 + c] = R[c * 3 + r] / sc[r];
+    const double sg[3] = {1.0, -1.0, 1.0};
+    double Q[3][3], sum = 0;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        Q[a][b] = 0;
+        for (int r = 0; r < 3; r++) Q[a][b] += sg[r] * mats[i][r * 3 + a] * mats[i][r * 3 + b];
+      }
+    for (double v : mats[i]) sum += v * v;
+    ConeBand& cb = bands[i];
+    cb.q[0] = Q[0][0]; cb.q[1] = Q[1][1]; cb.q[2] = Q[2][2];
+    cb.q[3] = 2 * Q[0][1]; cb.q[4] = 2 * Q[0][2]; cb.q[5] = 2 * Q[1][2];
+    cb.slack = 1e-11 * sum;
+    cb.prim = (uint32_t)i;
+  }
+  BandGrid grid = build_band_grid(bands, (size_t)1 << 28);
+  if (grid_n) *grid_n = grid.n;
+  if (entries) *entries = grid.items.size();
+  if (grid.n == 0) return 0;
+  int missing = 0;
+  const int n = grid.n;
+  for (int k = 0; k < n_dirs; k++) {
+    double d[3];
+    if ((k & 1) && n_bands > 0) {
+      // a direction on the surface of cone i: object direction (cos p, +-1, sin p) mapped to world
+      int i = (int)(next() % (uint64_t)n_bands);
+      double p = uni(0, 6.283185307179586), ol[3] = {cos(p), (next() & 1) ? 1.0 : -1.0, sin(p)};
+      // world = M^-1 object; M = diag(1/s) R^T, so M^-1 = R diag(s): solve by Cramer on the 3x3
+      const double* m = mats[i].data();
+      double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+      double inv[9] = {(m[4] * m[8] - m[5] * m[7]) / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
+                       (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
+                       (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
+      for (int r = 0; r < 3; r++) d[r] = inv[r * 3] * ol[0] + inv[r * 3 + 1] * ol[1] + inv[r * 3 + 2] * ol[2];
+    } else {
+      for (double& v : d) v = uni(-1, 1);
+    }
+    double len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (!(len > 1e-3)) continue;
+    for (double& v : d) v /= len;
+    const double xx = d[0] * d[0], yy = d[1] * d[1], zz = d[2] * d[2], xy = d[0] * d[1], xz = d[0] * d[2], yz = d[1] * d[2];
+    const double dd = xx + yy + zz;
+    int m = zz > yy ? 2 : 1;
+    m = xx >= (m == 2 ? zz : yy) ? 0 : m;
+    const double dm = d[m], da = d[(m + 1) % 3], dc = d[(m + 2) % 3];
+    const float inv = 1.0f / (float)dm, half_n = 0.5f * (float)n;
+    int iu = (int)floorf(((float)da * inv + 1.0f) * half_n), iv = (int)floorf(((float)dc * inv + 1.0f) * half_n);
+    iu = iu < 0 ? 0 : (iu >= n ? n - 1 : iu);
+    iv = iv < 0 ? 0 : (iv >= n ? n - 1 : iv);
+    const uint32_t cell = ((uint32_t)m * n + iv) * n + iu;
+    for (int i = 0; i < n_bands; i++) {
+      const ConeBand& cb = bands[i];
+      double a = cb.q[0] * xx + cb.q[1] * yy + cb.q[2] * zz + cb.q[3] * xy + cb.q[4] * xz + cb.q[5] * yz;
+      if (!(fabs(a) < FEQ_EPSILON * (1.0 + 1e-6) + cb.slack * dd)) continue;
+      bool found = std::binary_search(grid.items.begin() + grid.start[cell], grid.items.begin() + grid.start[cell + 1], (uint32_t)i);
+      if (!found) missing++;
+    }
+  }
+  return missing;
 }
 
 extern "C" int rt_scene_footprint(const rt_scene* s, uint64_t* scene_bytes, double* build_seconds) {

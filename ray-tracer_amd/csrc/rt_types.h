@@ -128,6 +128,8 @@ struct SceneDev {
   const QuadPrim* unbounded;  // tested for every ray (planes, infinite cylinders, very large shapes)
   const ConeBand* bands;      // bounded cones: direction pre-filter of their parallel-ray branch
   const QuadPrim* band_prims;
+  const uint32_t* band_start;  // direction grid over bands (band_grid.h), null when band_grid_n == 0
+  const uint32_t* band_items;
   const LeafShade* leaves;
   const XformDev* xforms;
   const TriShade* tri_shade;
@@ -137,6 +139,8 @@ struct SceneDev {
   int32_t n_unbounded;
   int32_t n_leaves;
   int32_t n_bands;
+  int32_t band_grid_n;
+  int32_t pad;
   double light_intensity[3];
   double light_position[3];
 };

@@ -60,6 +60,20 @@ def test_scene_matches_oracle(pkg, root, name):
     compare_images(out, stats, want, name)
 
 
+@pytest.mark.parametrize("name,size", [("example", (45, 31)), ("glass", (70, 50)), ("pattern", (36, 20)), ("egg", (1, 1)),
+                                       ("teapot", (101, 7))])
+def test_ragged_canvas_sizes(pkg, root, name, size):
+    """Widths that are not a multiple of 4 or of the 8-pixel block, partial tiles, a single pixel: the
+    framebuffer store has a packed path for whole block rows and a byte path for the rest."""
+    gpu, cpu = load_pair(pkg, root, name, size)
+    out, stats = gpu.render()
+    want = cpu.render(jobs=8)
+    compare_images(out, stats, want, name)
+    assert np.array_equal(out["rgb8"], orc.quantise(out["rgb64"]))
+    only8, _ = gpu.render(rgb64=False, hit_leaf=False)
+    assert np.array_equal(only8["rgb8"], out["rgb8"])
+
+
 def test_rendering_twice_is_bit_identical(pkg, root):
     gpu, _ = load_pair(pkg, root, "glass", (160, 90))
     a, _ = gpu.render()

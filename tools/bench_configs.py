@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""ms/frame and rays/s of every measured configuration on one GPU (not the headline bench: bench.py).
+
+  example 1080p, glass 4K, pattern 960x540, teapot 1080p, 1M-triangle heightfield 4K,
+  100k primitives 8K (camera sweep, --sweep-frames frames)
+
+Prints one JSON line per configuration.  The frame stays in HBM (rt_render into a device buffer).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import scenegen  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def run(pkg, name, path, size, frames, cameras=None, counters=False):
+    t0 = time.perf_counter()
+    scene = pkg.Scene.from_file(path, base_dir=ROOT, device=0)
+    load_s = time.perf_counter() - t0
+    if size:
+        scene.set_canvas(*size)
+    info, foot = scene.info(), scene.footprint()
+    w, h = info["width"], info["height"]
+    frame = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    for k in range(2):
+        scene.render_device(rgb8_ptr=frame.data_ptr())
+    torch.cuda.synchronize()
+    kernel_ms = render_ms = 0.0
+    rays = 0
+    t0 = time.perf_counter()
+    for k in range(frames):
+        if cameras:
+            scene.set_camera(w, h, 1.0472, *cameras[k % len(cameras)], [0.0, 1.0, 0.0])
+        st = scene.render_device(rgb8_ptr=frame.data_ptr())
+        kernel_ms += st.kernel_ms
+        render_ms += st.render_ms
+        rays += st.rays
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    out = {"config": name, "size": [w, h], "frames": frames, "ms_per_frame": wall / frames * 1e3,
+           "kernel_ms_per_frame": kernel_ms / frames, "rays_per_frame": rays / frames, "rays_per_s": rays / wall,
+           "generations": st.generations, "leaves": info["leaves"], "triangles": info["triangles"],
+           "scene_MB": foot["scene_bytes"] / 1e6, "bvh_build_s": foot["build_seconds"], "load_s": load_s}
+    if counters:
+        c = scene.render_device(rgb8_ptr=frame.data_ptr(), counters=True)
+        out["per_ray"] = {"node_visits": (c.node_visits + c.shadow_node_visits) / c.rays,
+                          "tri_tests": (c.tri_tests + c.shadow_tri_tests) / c.rays,
+                          "quadric_tests": (c.quadric_tests + c.shadow_quadric_tests) / c.rays}
+    print(json.dumps(out), flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=10)
+    ap.add_argument("--sweep-frames", type=int, default=60)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--counters", action="store_true")
+    args = ap.parse_args()
+    pkg = load_package()
+    want = set(args.only.split(",")) if args.only else None
+
+    def on(name):
+        return want is None or name in want
+
+    sc = os.path.join(ROOT, "scenes")
+    if on("example"):
+        run(pkg, "example 1080p", os.path.join(sc, "example.json"), None, args.frames, counters=args.counters)
+    if on("glass"):
+        run(pkg, "glass 4K", os.path.join(sc, "glass.json"), None, args.frames, counters=args.counters)
+    if on("pattern"):
+        run(pkg, "pattern 960x540", os.path.join(sc, "pattern.json"), None, args.frames, counters=args.counters)
+    if on("teapot"):
+        run(pkg, "teapot 1080p", os.path.join(sc, "teapot.json"), (1920, 1080), args.frames, counters=args.counters)
+    gen = tempfile.mkdtemp(prefix="rtgen")
+    if on("heightfield"):
+        path, tris = scenegen.heightfield(gen, cells=708)
+        run(pkg, "heightfield 1M triangles 4K", path, None, args.frames, counters=args.counters)
+    if on("primitives"):
+        path, n = scenegen.primitives(gen, count=100000)
+        cams = [scenegen.sweep_camera(k) for k in range(60)]
+        run(pkg, "100k primitives 8K sweep", path, None, args.sweep_frames, cameras=cams, counters=args.counters)
+
+
+if __name__ == "__main__":
+    main()
