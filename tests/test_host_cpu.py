@@ -97,3 +97,19 @@ def test_rendering_without_a_device_fails_loudly(pkg):
     s = pkg.Scene.from_file(os.path.join(ROOT, "scenes", "example.json"), base_dir=ROOT, device=None)
     with pytest.raises(pkg.RtError):
         s.render()
+
+
+@pytest.mark.parametrize("n_bands,n_dirs", [(20, 100), (300, 20000), (3000, 6000)])
+def test_cone_band_direction_index_is_conservative(pkg, n_bands, n_dirs):
+    """Every cone whose parallel-ray branch a direction triggers must be listed in that direction's
+    grid cell (host-only check of the index the kernels look up; half the directions lie on a cone)."""
+    amd, _ = pkg.libraries()
+    fn = amd.rt_selftest_band_grid
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
+    n, entries = ctypes.c_int(), ctypes.c_uint64()
+    missing = fn(n_bands, n_dirs, 0xC0DE + n_bands, ctypes.byref(n), ctypes.byref(entries))
+    assert missing == 0
+    if n_bands <= 32:
+        assert n.value == 0  # short lists are scanned, not indexed
+    else:
+        assert n.value >= 32 and entries.value > 0
