@@ -96,21 +96,26 @@ def main():
     copy_stream = torch.cuda.Stream(device=device)
     copy_done = [torch.cuda.Event() for _ in range(2)]
     gather = pkg.tiles.FrameGather(W, H, 3, torch.uint8, device, rank, world)
+    render_stream = torch.cuda.ExternalStream(scene.stream_ptr(), device=device)  # the library's own stream
     step_no = [0]
 
     def step():
+        # Frames are enqueued, not waited for (the scene spawns no rays, so a frame is one kernel):
+        # render k + 1 runs while frame k is gathered and copied; the streams are ordered by events.
         k = step_no[0] % 2
         step_no[0] += 1
         frame = frames[k]
-        copy_done[k].synchronize()  # the copy issued two frames ago has left this buffer
-        st = scene.render_device(rgb8_ptr=frame.data_ptr(), part=rank, n_parts=world)  # returns when rendered
+        copy_done[k].synchronize()  # the copy issued two frames ago has left this buffer (at most two frames in flight)
+        scene.render_device(rgb8_ptr=frame.data_ptr(), part=rank, n_parts=world, wait=False)
+        torch.cuda.current_stream().wait_stream(render_stream)
         gather(frame)  # RCCL gather of the other ranks' tiles into rank 0's frame
         if rank == 0:
             copy_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(copy_stream):
                 host_frames[k].copy_(frame, non_blocking=True)  # framebuffer on the host
                 copy_done[k].record()
-        return st
+        else:
+            copy_done[k].record()  # the gather has read the buffer
 
     def sync():
         torch.cuda.synchronize()
@@ -118,21 +123,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(8 + args.warmup):  # 8 priming frames: first launches load code objects and grow runtime pools
         step()
+    scene.wait()
     sync()
-    kernel_ms = render_ms = 0.0
-    kernel_n = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st = step()
-        kernel_ms += st.kernel_ms
-        render_ms += st.render_ms
-        kernel_n += st.kernel_launches
-    sync()
+        step()
+    t_enq = time.perf_counter() - t0
+    st = scene.wait()  # all frames rendered; sums of their ray counts and kernel times
+    t_wait = time.perf_counter() - t0
+    sync()             # ... and gathered and copied to the host
     elapsed = time.perf_counter() - t0
+    if os.environ.get("RT_BENCH_DEBUG"):
+        print("enqueue %.3f ms, +wait %.3f ms, +sync %.3f ms" % (t_enq * 1e3, t_wait * 1e3, elapsed * 1e3), file=sys.stderr)
+    kernel_ms, kernel_n = st.kernel_ms, st.kernel_launches
 
-    rays_step = torch.tensor([float(st.rays)], dtype=torch.float64, device=device)
+    rays_step = torch.tensor([float(st.rays) / args.steps], dtype=torch.float64, device=device)
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(rays_step, op=dist.ReduceOp.SUM)
@@ -219,8 +226,7 @@ def main():
         },
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
-        "breakdown_ms": {"frame": elapsed / args.steps * 1e3, "rt_render_call": render_ms / args.steps,
-                         "generation_kernels": kernel_ms / args.steps},
+        "breakdown_ms": {"frame": elapsed / args.steps * 1e3, "generation_kernels": kernel_ms / args.steps},
         "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": foot["build_seconds"], "scene_bytes": foot["scene_bytes"]},
     }
     print(json.dumps(out))

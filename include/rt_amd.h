@@ -162,7 +162,8 @@ typedef struct rt_stats {
 typedef struct rt_scene rt_scene;
 
 enum {
-  RT_FLAG_COUNTERS = 1 /* run the instrumented kernels and fill the work counters */
+  RT_FLAG_COUNTERS = 1, /* run the instrumented kernels and fill the work counters */
+  RT_FLAG_ASYNC = 2     /* rt_render only: enqueue the frame and return; see rt_scene_wait */
 };
 
 const char* rt_last_error(void);
@@ -187,6 +188,21 @@ int rt_scene_footprint(const rt_scene* scene, uint64_t* scene_bytes, double* bui
  * hit_leaf: primary hit leaf index or -1. */
 int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, uint32_t flags,
               uint8_t* rgb8_dev, double* rgb64_dev, int32_t* hit_leaf_dev, rt_stats* stats);
+
+/* Frames of a render loop, back to back.  With RT_FLAG_ASYNC, rt_render enqueues the frame on the
+ * scene's stream and returns at once (stats is not written); at most four frames are in flight, a
+ * fifth call waits for the oldest.  A scene whose materials spawn reflection or refraction rays
+ * needs the host between generations, so there the flag is ignored and the call blocks as usual.
+ * rt_scene_wait blocks until every enqueued frame is complete and returns the sums of their ray
+ * counts, kernel time and kernel launches since the previous wait (render_ms is not filled).
+ * Other entry points run on the same stream and are therefore ordered after frames in flight.  The reference renders one frame per
+ * process (src/main.rs:71); this pair has no counterpart there. */
+int rt_scene_wait(rt_scene* scene, rt_stats* total);
+
+/* The HIP stream (hipStream_t) all work of the scene is enqueued on, so that a caller can order
+ * its own streams after an asynchronous frame (hipStreamWaitEvent) or make a frame wait for a
+ * buffer to be free. */
+int rt_scene_stream(rt_scene* scene, void** hip_stream);
 
 /* Same, into host buffers (the library stages through device memory). */
 int rt_render_host(rt_scene* scene, const rt_camera* camera, int part, int n_parts, uint32_t flags,

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_HERE, "lib")
 
 RT_FLAG_COUNTERS = 1
+RT_FLAG_ASYNC = 2
 
 
 class RtError(RuntimeError):
@@ -85,6 +86,8 @@ def libraries():
     amd.rt_device_count.restype = i32
     amd.rt_scene_footprint.argtypes = [vp, C.POINTER(u64), dp]
     amd.rt_render.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
+    amd.rt_scene_wait.argtypes = [vp, C.POINTER(RtStats)]
+    amd.rt_scene_stream.argtypes = [vp, C.POINTER(vp)]
     amd.rt_render_host.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
     amd.rt_ray_for_pixel.argtypes = [vp, C.POINTER(RtCamera), u64, vp, vp]
     amd.rt_color_at.argtypes = [vp, u64, vp, i32, u32, vp, vp, C.POINTER(RtStats)]
@@ -177,13 +180,17 @@ class Scene:
         return self.info()["height"]
 
     def camera(self):
-        cam = RtCamera()
-        rc = self._host.rth_scene_camera(self._h, C.byref(cam))
-        if rc != 0:
-            raise RtError(rc, self._host.rth_last_error().decode())
+        cam = getattr(self, "_camera", None)
+        if cam is None:
+            cam = RtCamera()
+            rc = self._host.rth_scene_camera(self._h, C.byref(cam))
+            if rc != 0:
+                raise RtError(rc, self._host.rth_last_error().decode())
+            self._camera = cam
         return cam
 
     def set_canvas(self, width, height):
+        self._camera = None
         self._host.rth_scene_set_canvas(self._h, width, height)
 
     def set_camera(self, width, height, fov, cam_from, cam_to, cam_up):
@@ -191,6 +198,7 @@ class Scene:
         t = (C.c_double * 3)(*cam_to[:3])
         up = list(cam_up) + [0.0] * (4 - len(cam_up))
         u = (C.c_double * 4)(*up[:4])
+        self._camera = None
         self._host.rth_scene_set_camera(self._h, width, height, fov, f, t, u)
 
     def footprint(self):
@@ -228,14 +236,28 @@ class Scene:
             out["hit_leaf"] = al
         return out, st
 
-    def render_device(self, rgb8_ptr=0, rgb64_ptr=0, hit_leaf_ptr=0, part=0, n_parts=1, counters=False):
-        """rt_render into device buffers given by address (e.g. torch tensor .data_ptr())."""
+    def render_device(self, rgb8_ptr=0, rgb64_ptr=0, hit_leaf_ptr=0, part=0, n_parts=1, counters=False, wait=True):
+        """rt_render into device buffers given by address (e.g. torch tensor .data_ptr()).  With
+        wait=False the frame is only enqueued (RT_FLAG_ASYNC); collect with wait()."""
         cam = self.camera()
         st = RtStats()
-        self._check(self._amd.rt_render(self._dev(), C.byref(cam), part, n_parts, RT_FLAG_COUNTERS if counters else 0,
+        flags = (RT_FLAG_COUNTERS if counters else 0) | (0 if wait else RT_FLAG_ASYNC)
+        self._check(self._amd.rt_render(self._dev(), C.byref(cam), part, n_parts, flags,
                                         C.c_void_p(rgb8_ptr or None), C.c_void_p(rgb64_ptr or None),
                                         C.c_void_p(hit_leaf_ptr or None), C.byref(st)))
         return st
+
+    def wait(self):
+        """rt_scene_wait: blocks until the enqueued frames are complete; sums of their statistics."""
+        st = RtStats()
+        self._check(self._amd.rt_scene_wait(self._dev(), C.byref(st)))
+        return st
+
+    def stream_ptr(self):
+        """Address of the hipStream_t the scene's work runs on (for torch.cuda.ExternalStream)."""
+        p = C.c_void_p()
+        self._check(self._amd.rt_scene_stream(self._dev(), C.byref(p)))
+        return p.value or 0
 
     def parallel_render(self, jobs, out_path):
         rc = self._host.rth_parallel_render(self._h, jobs, str(out_path).encode())

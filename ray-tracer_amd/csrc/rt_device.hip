@@ -1200,6 +1200,19 @@ struct rt_scene {
   std::vector<uint32_t> h_tiles;
   uint32_t tiles_key[4] = {0, 0, 0, 0};  // hsize, vsize, part, n_parts of the uploaded tile table
   hipEvent_t ev[2 * MAX_GENERATIONS] = {};
+  // frames enqueued under RT_FLAG_ASYNC and not collected yet: a small ring, each slot with its own
+  // statistics block so consecutive frames do not share counters
+  struct FrameSlot {
+    unsigned long long* d_stats = nullptr;
+    unsigned long long* h_stats = nullptr;
+    hipEvent_t begin = nullptr, end = nullptr, done = nullptr;
+    bool pending = false;
+    uint64_t primary = 0;
+  };
+  static constexpr int FRAME_SLOTS = 4;
+  FrameSlot slots[FRAME_SLOTS];
+  int next_slot = 0;
+  rt_stats async_total{};
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -1461,6 +1474,12 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   if (s->stage) (void)hipFree(s->stage);
   for (hipEvent_t e : s->ev)
     if (e) (void)hipEventDestroy(e);
+  for (rt_scene::FrameSlot& f : s->slots) {
+    if (f.d_stats) (void)hipFree(f.d_stats);
+    if (f.h_stats) (void)hipHostFree(f.h_stats);
+    for (hipEvent_t e : {f.begin, f.end, f.done})
+      if (e) (void)hipEventDestroy(e);
+  }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -1636,6 +1655,13 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   HIP_TRY(hipHostMalloc((void**)&s->h_counts, (MAX_GENERATIONS + 1) * sizeof(uint32_t), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&s->h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
   for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
+  for (rt_scene::FrameSlot& f : s->slots) {
+    HIP_TRY(hipMalloc((void**)&f.d_stats, STAT_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void**)&f.h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&f.begin));
+    HIP_TRY(hipEventCreate(&f.end));
+    HIP_TRY(hipEventCreate(&f.done));
+  }
   return RT_OK;
 }
 
@@ -1788,12 +1814,13 @@ struct GenLaunch {
   const uint32_t* tiles;
   uint32_t tiles_x;
   ImageOut img;
+  unsigned long long* stats;
 };
 
 template <int STACK, bool COUNT>
 void launch_generation_mode(rt_scene* s, int mode, const GenLaunch& a) {
   dim3 grid(blocks_for(a.n)), block(BLOCK);
-#define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_capacity, a.remaining, a.next_count, s->d_stats, a.cam, a.tiles, a.tiles_x, a.img
+#define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_capacity, a.remaining, a.next_count, a.stats, a.cam, a.tiles, a.tiles_x, a.img
   switch (mode) {
     case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0>), grid, block, 0, s->stream, RT_GEN_ARGS); break;
     case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1>), grid, block, 0, s->stream, RT_GEN_ARGS); break;
@@ -1834,6 +1861,85 @@ struct PipelineIn {
   ImageOut img{nullptr, nullptr, nullptr};
 };
 
+void decode_stats(const unsigned long long* h, rt_stats* stats) {
+  unsigned long long sums[3] = {0, 0, 0};
+  for (int k = 0; k < 3; k++)
+    for (int j = 0; j < STAT_SLOTS; j++) sums[k] += h[STAT_RAYS + k * STAT_SLOTS + j];
+  stats->shadow = sums[0];
+  stats->reflect = sums[1];
+  stats->refract = sums[2];
+  stats->node_visits = h[0];
+  stats->tri_tests = h[1];
+  stats->quadric_tests = h[2];
+  stats->gate_tests = h[3];
+  stats->shadow_node_visits = h[4];
+  stats->shadow_tri_tests = h[5];
+  stats->shadow_quadric_tests = h[6];
+  stats->shadow_gate_tests = h[7];
+}
+
+// Waits for one asynchronous frame and adds its statistics to the scene's running total.
+int collect_frame(rt_scene* s, rt_scene::FrameSlot& f) {
+  if (!f.pending) return RT_OK;
+  HIP_TRY(hipEventSynchronize(f.done));
+  f.pending = false;
+  rt_stats one{};
+  decode_stats(f.h_stats, &one);
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, f.begin, f.end));
+  rt_stats& t = s->async_total;
+  t.primary += f.primary;
+  t.shadow += one.shadow; t.reflect += one.reflect; t.refract += one.refract;
+  t.kernel_ms += ms;
+  t.kernel_launches += 1;
+  t.generations += 1;
+  t.node_visits += one.node_visits; t.tri_tests += one.tri_tests;
+  t.quadric_tests += one.quadric_tests; t.gate_tests += one.gate_tests;
+  t.shadow_node_visits += one.shadow_node_visits; t.shadow_tri_tests += one.shadow_tri_tests;
+  t.shadow_quadric_tests += one.shadow_quadric_tests; t.shadow_gate_tests += one.shadow_gate_tests;
+  return RT_OK;
+}
+
+int collect_all(rt_scene* s) {
+  for (int k = 0; k < rt_scene::FRAME_SLOTS; k++) {
+    int rc = collect_frame(s, s->slots[(s->next_slot + k) % rt_scene::FRAME_SLOTS]);
+    if (rc) return rc;
+  }
+  return RT_OK;
+}
+
+// One camera frame of a scene that spawns no rays: a single kernel, nothing to read back, so the
+// frame is only enqueued.
+int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
+  rt_scene::FrameSlot& f = s->slots[s->next_slot];
+  int rc = collect_frame(s, f);  // the slot's previous frame, FRAME_SLOTS frames ago
+  if (rc) return rc;
+  s->next_slot = (s->next_slot + 1) % rt_scene::FRAME_SLOTS;
+  HIP_TRY(hipMemsetAsync(f.d_stats, 0, STAT_WORDS * sizeof(unsigned long long), s->stream));
+  GenLaunch a;
+  a.cur = s->gens[0].view;
+  a.next = s->gens[1].view;
+  a.n = in.n0;
+  a.next_capacity = 0;
+  a.remaining = 0;
+  a.next_count = s->d_counts;
+  a.cam = in.cam;
+  a.tiles = in.tiles;
+  a.tiles_x = in.tiles_x;
+  a.img = in.img;
+  a.stats = f.d_stats;
+  HIP_TRY(hipEventRecord(f.begin, s->stream));
+  launch_generation(s, 0, (in.flags & RT_FLAG_COUNTERS) != 0, a);
+  HIP_TRY(hipEventRecord(f.end, s->stream));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(f.h_stats, f.d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                         s->stream));
+  HIP_TRY(hipEventRecord(f.done, s->stream));
+  f.primary = primary;
+  f.pending = true;
+  return RT_OK;
+}
+
 // Runs the generations, resolves colours back into generation 0 and, for camera
 // rays, writes the image.  Fills the device-side fields of stats.
 int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
@@ -1866,6 +1972,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     a.tiles = in.tiles;
     a.tiles_x = in.tiles_x;
     a.img = in.img;
+    a.stats = s->d_stats;
     int mode = (g == 0 && in.camera) ? (direct ? 0 : 1) : 2;
     HIP_TRY(hipEventRecord(s->ev[g * 2 + 0], s->stream));
     launch_generation(s, mode, count, a);
@@ -1887,20 +1994,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
                          s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (stats) {
-    unsigned long long sums[3] = {0, 0, 0};
-    for (int k = 0; k < 3; k++)
-      for (int j = 0; j < STAT_SLOTS; j++) sums[k] += s->h_stats[STAT_RAYS + k * STAT_SLOTS + j];
-    stats->shadow = sums[0];
-    stats->reflect = sums[1];
-    stats->refract = sums[2];
-    stats->node_visits = s->h_stats[0];
-    stats->tri_tests = s->h_stats[1];
-    stats->quadric_tests = s->h_stats[2];
-    stats->gate_tests = s->h_stats[3];
-    stats->shadow_node_visits = s->h_stats[4];
-    stats->shadow_tri_tests = s->h_stats[5];
-    stats->shadow_quadric_tests = s->h_stats[6];
-    stats->shadow_gate_tests = s->h_stats[7];
+    decode_stats(s->h_stats, stats);
     stats->kernel_ms = 0;
     stats->kernel_launches = 0;
     stats->generations = (uint64_t)last + 1;
@@ -1941,6 +2035,9 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   uint32_t tiles_x = (camera->hsize + TILE - 1) / TILE, tiles_y = (camera->vsize + TILE - 1) / TILE;
   const uint32_t key[4] = {camera->hsize, camera->vsize, (uint32_t)part, (uint32_t)n_parts};
   if (memcmp(key, s->tiles_key, sizeof(key)) != 0) {
+    int rcw = collect_all(s);  // frames in flight still read the current tile table
+    if (rcw) return rcw;
+    HIP_TRY(hipStreamSynchronize(s->stream));
     s->h_tiles.clear();
     for (uint32_t ty = 0; ty < tiles_y; ty++)
       for (uint32_t tx = 0; tx < tiles_x; tx++)
@@ -1969,18 +2066,37 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   in.tiles = s->d_tiles;
   in.tiles_x = tiles_x;
   in.img = ImageOut{rgb8_dev, rgb64_dev, hit_leaf_dev};
-  int rc = run_pipeline(s, in, stats);
+  uint64_t valid = 0;
+  for (uint32_t t : s->h_tiles) {
+    uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * TILE;
+    uint32_t w = std::min<uint32_t>(TILE, camera->hsize - x0), h = std::min<uint32_t>(TILE, camera->vsize - y0);
+    valid += (uint64_t)w * h;
+  }
+  if ((flags & RT_FLAG_ASYNC) && s->max_children == 0) return enqueue_direct_frame(s, in, valid);
+  int rc = collect_all(s);  // frames still in flight finish first
+  if (rc) return rc;
+  rc = run_pipeline(s, in, stats);
   if (rc) return rc;
   if (stats) {
-    uint64_t valid = 0;
-    for (uint32_t t : s->h_tiles) {
-      uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * TILE;
-      uint32_t w = std::min<uint32_t>(TILE, camera->hsize - x0), h = std::min<uint32_t>(TILE, camera->vsize - y0);
-      valid += (uint64_t)w * h;
-    }
     stats->primary = valid;
     stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   }
+  return RT_OK;
+}
+
+extern "C" int rt_scene_wait(rt_scene* s, rt_stats* total) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = collect_all(s);
+  if (rc) return rc;
+  if (total) *total = s->async_total;
+  s->async_total = rt_stats{};
+  return RT_OK;
+}
+
+extern "C" int rt_scene_stream(rt_scene* s, void** hip_stream) {
+  if (!s || !hip_stream) return fail(RT_ERR_INVALID, "null argument");
+  *hip_stream = (void*)s->stream;
   return RT_OK;
 }
 
@@ -1996,7 +2112,7 @@ extern "C" int rt_render_host(rt_scene* s, const rt_camera* camera, int part, in
   char* base = (char*)s->stage;
   HIP_TRY(hipMemsetAsync(base, 0, offl + bl, s->stream));
   if (hit_leaf) HIP_TRY(hipMemsetAsync(base + offl, 0xFF, bl, s->stream));
-  rc = rt_render(s, camera, part, n_parts, flags, rgb8 ? (uint8_t*)base : nullptr,
+  rc = rt_render(s, camera, part, n_parts, flags & ~(uint32_t)RT_FLAG_ASYNC, rgb8 ? (uint8_t*)base : nullptr,
                  rgb64 ? (double*)(base + off64) : nullptr, hit_leaf ? (int32_t*)(base + offl) : nullptr, stats);
   if (rc) return rc;
   if (rgb8) HIP_TRY(hipMemcpy(rgb8, base, b8, hipMemcpyDeviceToHost));

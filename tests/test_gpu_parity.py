@@ -131,3 +131,29 @@ def test_is_shadowed_matches_oracle(pkg, root):
     rng = np.random.default_rng(3)
     pts = rng.uniform(-6, 6, (2000, 3))
     assert np.array_equal(gpu.is_shadowed(pts), cpu.is_shadowed(pts))
+
+
+def test_enqueued_frames_equal_blocking_frames(pkg, root):
+    """RT_FLAG_ASYNC: six frames enqueued back to back into two device buffers; rt_scene_wait returns
+    the summed statistics; the pixels equal those of a blocking render."""
+    import torch
+
+    gpu, _ = load_pair(pkg, root, "teapot", (200, 112))
+    want, st1 = gpu.render(rgb64=False, hit_leaf=False)
+    bufs = [torch.zeros((112, 200, 3), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    for k in range(6):
+        gpu.render_device(rgb8_ptr=bufs[k % 2].data_ptr(), wait=False)
+    total = gpu.wait()
+    assert total.kernel_launches == 6 and total.primary == 6 * st1.primary and total.shadow == 6 * st1.shadow
+    assert total.kernel_ms > 0
+    for b in bufs:
+        assert np.array_equal(b.cpu().numpy(), want["rgb8"])
+    again = gpu.wait()  # nothing in flight: zeros
+    assert again.kernel_launches == 0 and again.primary == 0
+    # a scene that spawns rays ignores the flag and blocks
+    glass, _ = load_pair(pkg, root, "glass", (64, 36))
+    ref8, st = glass.render(rgb64=False, hit_leaf=False)
+    buf = torch.zeros((36, 64, 3), dtype=torch.uint8, device="cuda:0")
+    st2 = glass.render_device(rgb8_ptr=buf.data_ptr(), wait=False)
+    assert st2.reflect == st.reflect and np.array_equal(buf.cpu().numpy(), ref8["rgb8"])
