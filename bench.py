@@ -75,14 +75,20 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (
             args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # RT_BENCH_BACKEND=gloo rehearses the multi-rank path on a machine with fewer GPUs than ranks
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     pkg = load_package()
     t_load = time.perf_counter()
-    scene = pkg.Scene.from_file(args.scene, base_dir=ROOT, device=local_rank)
+    scene = pkg.Scene.from_file(args.scene, base_dir=ROOT, device=dev_index)
     scene.set_canvas(args.width, args.height)
     load_s = time.perf_counter() - t_load
     info, foot = scene.info(), scene.footprint()
@@ -90,12 +96,13 @@ def main():
 
     # Two device frames and two pinned host frames: the copy of frame k to the host runs on its
     # own stream while frame k + 1 renders, so the framebuffer of every frame still reaches the host
-    # inside the timed region but off the critical path.
-    frames = [torch.zeros((H, W, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+    # inside the timed region but off the critical path.  With several ranks every rank renders its
+    # tiles in the compact layout and rank 0 gathers them (one RCCL gather + one indexed copy).
+    gather = pkg.tiles.FrameGather(W, H, device, rank, world)
+    frames = [torch.zeros((H, W, 3), dtype=torch.uint8, device=device) for _ in range(2)] if world == 1 else None
     host_frames = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)] if rank == 0 else None
     copy_stream = torch.cuda.Stream(device=device)
-    copy_done = [torch.cuda.Event() for _ in range(2)]
-    gather = pkg.tiles.FrameGather(W, H, 3, torch.uint8, device, rank, world)
+    buffer_free = [torch.cuda.Event() for _ in range(2)]
     render_stream = torch.cuda.ExternalStream(scene.stream_ptr(), device=device)  # the library's own stream
     step_no = [0]
 
@@ -104,18 +111,22 @@ def main():
         # render k + 1 runs while frame k is gathered and copied; the streams are ordered by events.
         k = step_no[0] % 2
         step_no[0] += 1
-        frame = frames[k]
-        copy_done[k].synchronize()  # the copy issued two frames ago has left this buffer (at most two frames in flight)
-        scene.render_device(rgb8_ptr=frame.data_ptr(), part=rank, n_parts=world, wait=False)
-        torch.cuda.current_stream().wait_stream(render_stream)
-        gather(frame)  # RCCL gather of the other ranks' tiles into rank 0's frame
+        buffer_free[k].synchronize()  # frame k - 2 has left these buffers (at most two frames in flight)
+        if world == 1:
+            frame = frames[k]
+            scene.render_device(rgb8_ptr=frame.data_ptr(), wait=False)
+            torch.cuda.current_stream().wait_stream(render_stream)
+        else:
+            scene.render_device(rgb8_ptr=gather.mine[k].data_ptr(), part=rank, n_parts=world, wait=False, compact=True)
+            torch.cuda.current_stream().wait_stream(render_stream)
+            frame = gather(k)  # rank 0: the whole frame
         if rank == 0:
             copy_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(copy_stream):
                 host_frames[k].copy_(frame, non_blocking=True)  # framebuffer on the host
-                copy_done[k].record()
+                buffer_free[k].record()
         else:
-            copy_done[k].record()  # the gather has read the buffer
+            buffer_free[k].record()
 
     def sync():
         torch.cuda.synchronize()
@@ -150,7 +161,8 @@ def main():
     # ---- roofline of the dominant kernel (k_generation, this rank's part): duration from the HIP
     # events the library records on its stream around every launch of the timed loop; work from one
     # extra, instrumented frame
-    cst = scene.render_device(rgb8_ptr=frames[0].data_ptr(), part=rank, n_parts=world, counters=True)
+    scratch = frames[0] if world == 1 else torch.zeros((H, W, 3), dtype=torch.uint8, device=device)
+    cst = scene.render_device(rgb8_ptr=scratch.data_ptr(), part=rank, n_parts=world, counters=True)
     flops, nbytes, onchip, events = kernel_work(cst, foot["scene_bytes"])
     launches = max(1, cst.kernel_launches)
     avg_ms = kernel_ms / max(1, kernel_n)

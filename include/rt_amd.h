@@ -163,7 +163,8 @@ typedef struct rt_scene rt_scene;
 
 enum {
   RT_FLAG_COUNTERS = 1, /* run the instrumented kernels and fill the work counters */
-  RT_FLAG_ASYNC = 2     /* rt_render only: enqueue the frame and return; see rt_scene_wait */
+  RT_FLAG_ASYNC = 2,    /* rt_render only: enqueue the frame and return; see rt_scene_wait */
+  RT_FLAG_COMPACT = 4   /* rt_render only: rgb8_dev receives just this part's pixels, see rt_render */
 };
 
 const char* rt_last_error(void);
@@ -185,7 +186,13 @@ int rt_scene_footprint(const rt_scene* scene, uint64_t* scene_bytes, double* bui
  * are full-size W*H images in which only this part's pixels are written; any
  * of them may be NULL.  rgb8: the quantised bytes of `Canvas::save`
  * (ceil(clamp(c*255)), src/canvas.rs:60-62); rgb64: the f64 colours;
- * hit_leaf: primary hit leaf index or -1. */
+ * hit_leaf: primary hit leaf index or -1.
+ * With RT_FLAG_COMPACT (rgb8 only) the buffer holds only the part's own tiles, 3072 bytes per tile
+ * in the order the part owns them (row-major over tiles), and inside a tile sixteen 8x8 pixel
+ * blocks (block b at columns 8 (b % 4), rows 8 (b / 4)), each row-major; pixels of a tile that
+ * fall outside the image are left unwritten.  This is the unit a multi-GPU host gathers: one
+ * contiguous buffer per GPU (the reference gathers per pixel through a channel,
+ * src/parallel.rs:44-49). */
 int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, uint32_t flags,
               uint8_t* rgb8_dev, double* rgb64_dev, int32_t* hit_leaf_dev, rt_stats* stats);
 

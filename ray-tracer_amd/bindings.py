@@ -16,6 +16,7 @@ _LIBDIR = os.path.join(_HERE, "lib")
 
 RT_FLAG_COUNTERS = 1
 RT_FLAG_ASYNC = 2
+RT_FLAG_COMPACT = 4
 
 
 class RtError(RuntimeError):
@@ -236,12 +237,13 @@ class Scene:
             out["hit_leaf"] = al
         return out, st
 
-    def render_device(self, rgb8_ptr=0, rgb64_ptr=0, hit_leaf_ptr=0, part=0, n_parts=1, counters=False, wait=True):
+    def render_device(self, rgb8_ptr=0, rgb64_ptr=0, hit_leaf_ptr=0, part=0, n_parts=1, counters=False, wait=True,
+                      compact=False):
         """rt_render into device buffers given by address (e.g. torch tensor .data_ptr()).  With
         wait=False the frame is only enqueued (RT_FLAG_ASYNC); collect with wait()."""
         cam = self.camera()
         st = RtStats()
-        flags = (RT_FLAG_COUNTERS if counters else 0) | (0 if wait else RT_FLAG_ASYNC)
+        flags = (RT_FLAG_COUNTERS if counters else 0) | (0 if wait else RT_FLAG_ASYNC) | (RT_FLAG_COMPACT if compact else 0)
         self._check(self._amd.rt_render(self._dev(), C.byref(cam), part, n_parts, flags,
                                         C.c_void_p(rgb8_ptr or None), C.c_void_p(rgb64_ptr or None),
                                         C.c_void_p(hit_leaf_ptr or None), C.byref(st)))

@@ -614,6 +614,7 @@ struct ImageOut {
   uint8_t* rgb8;
   double* rgb64;
   int32_t* hit_leaf;
+  uint32_t compact;  // rgb8 holds this part's pixels in ray order (3 bytes at 3 i) instead of at y * width + x
 };
 
 constexpr int TILE = 32;  // multi-GPU partition granule, pixels per side
@@ -800,9 +801,10 @@ DEV uint8_t quantise(double c) {
 
 // Canvas::write_pixel for the 8x8 pixel block of a wave; all 64 lanes call it together.  The bytes
 // of one block row (8 pixels, 24 bytes) are gathered across lanes and stored as six dwords, so the
-// framebuffer leaves the chip as full dwords instead of three single-byte stores per pixel.
-DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y, bool active, double r, double g,
-                     double b, int leaf) {
+// framebuffer leaves the chip as full dwords instead of three single-byte stores per pixel.  In the
+// compact layout the 64 pixels of the wave are contiguous (192 bytes, 48 dwords).
+DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y, uint32_t i, bool active, double r,
+                     double g, double b, int leaf) {
   const size_t p = (size_t)y * hsize + x;
   if (active) {
     if (img.rgb64) {
@@ -812,7 +814,24 @@ DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y
   }
   if (!img.rgb8) return;
   const uint32_t v = (uint32_t)quantise(r) | ((uint32_t)quantise(g) << 8) | ((uint32_t)quantise(b) << 16);
-  const uint32_t lane = thread_in_block() & 63u, col = lane & 7u, row_base = lane & ~7u;
+  const uint32_t lane = thread_in_block() & 63u;
+  if (img.compact) {
+    // dword `lane` (0..47) of the wave's 192 bytes holds bytes 4 lane .. 4 lane + 3: pixels p0 and p0 + 1
+    const uint32_t p0 = (4u * lane) / 3u, shift = 8u * (4u * lane - 3u * p0);
+    const uint32_t lo = __shfl(v, (int)(p0 < 63u ? p0 : 63u));
+    const uint32_t hi = __shfl(v, (int)(p0 + 1u < 63u ? p0 + 1u : 63u));
+    if (((uintptr_t)img.rgb8 & 3u) == 0u) {  // wave-uniform; i - lane is a multiple of 64
+      if (lane < 48u) {
+        const unsigned long long cat = (unsigned long long)lo | ((unsigned long long)hi << 24);
+        reinterpret_cast<uint32_t*>(img.rgb8 + (size_t)(i - lane) * 3u)[lane] = (uint32_t)(cat >> shift);
+      }
+    } else {
+      img.rgb8[(size_t)i * 3 + 0] = (uint8_t)v; img.rgb8[(size_t)i * 3 + 1] = (uint8_t)(v >> 8);
+      img.rgb8[(size_t)i * 3 + 2] = (uint8_t)(v >> 16);
+    }
+    return;
+  }
+  const uint32_t col = lane & 7u, row_base = lane & ~7u;
   // dword `col` (0..5) of the row holds bytes 4 col .. 4 col + 3, which belong to pixels p0 and p0 + 1
   const uint32_t p0 = (4u * col) / 3u, shift = 8u * (4u * col - 3u * p0);
   const uint32_t lo = __shfl(v, (int)(row_base + (p0 < 7u ? p0 : 7u)));
@@ -1027,7 +1046,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     out_b = SQ.found ? ab : lb;
   }
   if (MODE == 0) {
-    write_pixel(img, cam.hsize, px, py, active, out_r, out_g, out_b, leaf);
+    write_pixel(img, cam.hsize, px, py, i, active, out_r, out_g, out_b, leaf);
   } else if (i < n) {
     g.cr[i] = out_r; g.cg[i] = out_g; g.cb[i] = out_b;
   }
@@ -1086,7 +1105,7 @@ __global__ void __launch_bounds__(BLOCK)
     r = g.cr[i]; gg = g.cg[i]; b = g.cb[i];
     leaf = g.leaf[i];
   }
-  write_pixel(img, cam.hsize, x, y, active, r, gg, b, leaf);
+  write_pixel(img, cam.hsize, x, y, i, active, r, gg, b, leaf);
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -1820,11 +1839,12 @@ struct GenLaunch {
 template <int STACK, bool COUNT>
 void launch_generation_mode(rt_scene* s, int mode, const GenLaunch& a) {
   dim3 grid(blocks_for(a.n)), block(BLOCK);
+  static const unsigned extra_lds = getenv("RT_AMD_EXTRA_LDS") ? (unsigned)atoi(getenv("RT_AMD_EXTRA_LDS")) : 0u;
 #define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_capacity, a.remaining, a.next_count, a.stats, a.cam, a.tiles, a.tiles_x, a.img
   switch (mode) {
-    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0>), grid, block, 0, s->stream, RT_GEN_ARGS); break;
-    case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1>), grid, block, 0, s->stream, RT_GEN_ARGS); break;
-    default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2>), grid, block, 0, s->stream, RT_GEN_ARGS); break;
+    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
+    case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
+    default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
   }
 #undef RT_GEN_ARGS
 }
@@ -1858,7 +1878,7 @@ struct PipelineIn {
   CameraDev cam{};
   const uint32_t* tiles = nullptr;
   uint32_t tiles_x = 0;
-  ImageOut img{nullptr, nullptr, nullptr};
+  ImageOut img{nullptr, nullptr, nullptr, 0};
 };
 
 void decode_stats(const unsigned long long* h, rt_stats* stats) {
@@ -2065,7 +2085,9 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   in.cam = camera_dev(camera);
   in.tiles = s->d_tiles;
   in.tiles_x = tiles_x;
-  in.img = ImageOut{rgb8_dev, rgb64_dev, hit_leaf_dev};
+  if ((flags & RT_FLAG_COMPACT) && (rgb64_dev || hit_leaf_dev || !rgb8_dev))
+    return fail(RT_ERR_INVALID, "the compact layout is for rgb8 only");
+  in.img = ImageOut{rgb8_dev, rgb64_dev, hit_leaf_dev, (flags & RT_FLAG_COMPACT) ? 1u : 0u};
   uint64_t valid = 0;
   for (uint32_t t : s->h_tiles) {
     uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * TILE;
@@ -2112,7 +2134,7 @@ extern "C" int rt_render_host(rt_scene* s, const rt_camera* camera, int part, in
   char* base = (char*)s->stage;
   HIP_TRY(hipMemsetAsync(base, 0, offl + bl, s->stream));
   if (hit_leaf) HIP_TRY(hipMemsetAsync(base + offl, 0xFF, bl, s->stream));
-  rc = rt_render(s, camera, part, n_parts, flags & ~(uint32_t)RT_FLAG_ASYNC, rgb8 ? (uint8_t*)base : nullptr,
+  rc = rt_render(s, camera, part, n_parts, flags & ~(uint32_t)(RT_FLAG_ASYNC | RT_FLAG_COMPACT), rgb8 ? (uint8_t*)base : nullptr,
                  rgb64 ? (double*)(base + off64) : nullptr, hit_leaf ? (int32_t*)(base + offl) : nullptr, stats);
   if (rc) return rc;
   if (rgb8) HIP_TRY(hipMemcpy(rgb8, base, b8, hipMemcpyDeviceToHost));

@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 
 TILE = 32
+TILE_PIXELS = TILE * TILE
 
 
 def part_pixel_index(width, height, part, n_parts, device="cpu"):
@@ -19,24 +20,77 @@ def part_pixel_index(width, height, part, n_parts, device="cpu"):
     return (ys * width + xs)[owner == part].reshape(-1)
 
 
+def part_tiles(width, height, part, n_parts):
+    """Tile numbers (ty * tiles_x + tx) owned by `part`, in the order rt_render walks them."""
+    tiles_x, tiles_y = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    ty, tx = torch.meshgrid(torch.arange(tiles_y), torch.arange(tiles_x), indexing="ij")
+    mine = ((tx + ty) % n_parts) == part
+    return (ty * tiles_x + tx)[mine].reshape(-1), tiles_x
+
+
+def compact_pixel_index(width, height, part, n_parts, device="cpu", outside=-1):
+    """For every slot of the compact rgb8 layout of rt_render (RT_FLAG_COMPACT): the linear pixel index
+    y * width + x it holds, or `outside` for slots of a tile that fall outside the image.  Slot order:
+    tile by tile, inside a tile sixteen 8x8 blocks (block b at columns 8 (b % 4), rows 8 (b // 4)),
+    each block row-major."""
+    tiles, tiles_x = part_tiles(width, height, part, n_parts)
+    slot = torch.arange(TILE_PIXELS)
+    block, lane = slot // 64, slot % 64
+    dx = (block % 4) * 8 + lane % 8
+    dy = (block // 4) * 8 + lane // 8
+    x = (tiles % tiles_x)[:, None] * TILE + dx[None, :]
+    y = (tiles // tiles_x)[:, None] * TILE + dy[None, :]
+    idx = y * width + x
+    idx[(x >= width) | (y >= height)] = outside
+    return idx.reshape(-1).to(device)
+
+
 class FrameGather:
-    """Gathers every rank's tiles of an (H, W, C) frame into rank 0's frame, in place."""
+    """Collects the parts of a frame on rank 0.
 
-    def __init__(self, width, height, channels, dtype, device, rank, world):
-        self.rank, self.world = rank, world
-        self.idx = [part_pixel_index(width, height, p, world, device) for p in range(world)]
-        n_max = max(int(i.numel()) for i in self.idx)
-        self.mine = torch.zeros((n_max, channels), dtype=dtype, device=device)
-        self.parts = [torch.zeros((n_max, channels), dtype=dtype, device=device) for _ in range(world)] if rank == 0 else None
+    Every rank renders its part in the compact layout into `mine[k]` (k = 0 / 1, two buffers so that
+    frame n + 1 can be rendered while frame n is still being gathered); `__call__(k, frame)` gathers
+    the buffers to rank 0 and, there, scatters them into the (H, W, 3) uint8 `frame` with one indexed
+    copy.  With one rank nothing is exchanged: the frame is rendered in place.
+    """
 
-    def __call__(self, frame):
+    def __init__(self, width, height, device, rank, world, backend=None):
+        self.rank, self.world, self.device = rank, world, device
+        self.width, self.height = width, height
+        self.backend = backend or (dist.get_backend() if world > 1 else None)
+        if world == 1:
+            return
+        n_pix = width * height
+        idx = [compact_pixel_index(width, height, p, world, outside=n_pix) for p in range(world)]
+        self.slots = [int(i.numel()) for i in idx]
+        n_max = max(self.slots)
+        self.mine = [torch.zeros((n_max, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+        if rank == 0:
+            # one index for all parts, padded slots and out-of-image slots land on a spare row
+            pad = torch.full((world, n_max), n_pix, dtype=torch.int64)
+            for p in range(world):
+                pad[p, : self.slots[p]] = idx[p]
+            self.index = pad.reshape(-1).to(device)
+            self.recv = [torch.zeros((world, n_max, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+            self.canvas = [torch.zeros((n_pix + 1, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+
+    def frame(self, k):
+        """(H, W, 3) view of buffer k on rank 0 after __call__(k)."""
+        return self.canvas[k][:-1].view(self.height, self.width, 3)
+
+    def __call__(self, k):
         if self.world == 1:
-            return frame
-        flat = frame.view(-1, frame.shape[-1])
-        n = self.idx[self.rank].numel()
-        self.mine[:n] = flat[self.idx[self.rank]]
-        dist.gather(self.mine, self.parts, dst=0)
+            return None
+        if self.backend == "gloo" and self.mine[k].is_cuda:
+            # rehearsal on a machine without RCCL peers: stage through host memory
+            mine = self.mine[k].cpu()
+            parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(mine, parts, dst=0)
+            if self.rank == 0:
+                self.recv[k].copy_(torch.stack(parts))
+        else:
+            dist.gather(self.mine[k], list(self.recv[k].unbind(0)) if self.rank == 0 else None, dst=0)
         if self.rank == 0:
-            for p in range(1, self.world):
-                flat[self.idx[p]] = self.parts[p][: self.idx[p].numel()]
-        return frame
+            self.canvas[k].index_copy_(0, self.index, self.recv[k].view(-1, 3))
+            return self.frame(k)
+        return None

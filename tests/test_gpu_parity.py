@@ -157,3 +157,23 @@ def test_enqueued_frames_equal_blocking_frames(pkg, root):
     buf = torch.zeros((36, 64, 3), dtype=torch.uint8, device="cuda:0")
     st2 = glass.render_device(rgb8_ptr=buf.data_ptr(), wait=False)
     assert st2.reflect == st.reflect and np.array_equal(buf.cpu().numpy(), ref8["rgb8"])
+
+
+@pytest.mark.parametrize("size,n_parts", [((200, 112), 3), ((70, 50), 2), ((1920, 1080), 8)])
+def test_compact_parts_rebuild_the_frame(pkg, root, size, n_parts):
+    """RT_FLAG_COMPACT: every part rendered into its own contiguous buffer, scattered back with
+    tiles.compact_pixel_index, equals the frame rendered in one piece."""
+    import torch
+
+    gpu, _ = load_pair(pkg, root, "teapot", size)
+    want, _ = gpu.render(rgb64=False, hit_leaf=False)
+    w, h = size
+    canvas = torch.zeros((w * h + 1, 3), dtype=torch.uint8, device="cuda:0")
+    for part in range(n_parts):
+        idx = pkg.tiles.compact_pixel_index(w, h, part, n_parts, device="cuda:0", outside=w * h)
+        buf = torch.zeros((idx.numel(), 3), dtype=torch.uint8, device="cuda:0")
+        gpu.render_device(rgb8_ptr=buf.data_ptr(), part=part, n_parts=n_parts, compact=True)
+        canvas.index_copy_(0, idx, buf)
+    assert np.array_equal(canvas[:-1].view(h, w, 3).cpu().numpy(), want["rgb8"])
+    with pytest.raises(pkg.RtError):
+        gpu.render_device(rgb64_ptr=canvas.data_ptr(), compact=True)  # the compact layout is rgb8 only

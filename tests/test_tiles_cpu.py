@@ -17,6 +17,11 @@ def test_parts_partition_the_image(pkg):
             ys, xs = idx // w, idx % w
             assert bool((((xs // 32) + (ys // 32)) % n == p).all())
         assert bool((seen == 1).all())
+        # the compact layout lists the same pixels, each once, plus the out-of-image slots of edge tiles
+        for p in range(n):
+            c = pkg.tiles.compact_pixel_index(w, h, p, n)
+            assert c.numel() % 1024 == 0
+            assert torch.equal(torch.sort(c[c >= 0]).values, pkg.tiles.part_pixel_index(w, h, p, n))
     sizes = [pkg.tiles.part_pixel_index(1920, 1080, p, 8).numel() for p in range(8)]
     assert max(sizes) - min(sizes) <= 0.05 * max(sizes)  # balanced to a few percent
 
@@ -41,13 +46,19 @@ def _worker(rank, world, port, w, h, out):
     try:
         ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
         truth = torch.stack([xs % 251, ys % 241, (xs * 7 + ys * 13) % 239], dim=-1).to(torch.uint8)
-        frame = torch.zeros((h, w, 3), dtype=torch.uint8)
-        mine = pkg.tiles.part_pixel_index(w, h, rank, world)
-        frame.view(-1, 3)[mine] = truth.view(-1, 3)[mine]  # what this rank's GPU would have rendered
-        gather = pkg.tiles.FrameGather(w, h, 3, torch.uint8, "cpu", rank, world)
-        gather(frame)
+        gather = pkg.tiles.FrameGather(w, h, "cpu", rank, world)
+        ok = True
+        for k in (0, 1, 0):  # both buffer sets, and reuse
+            # what this rank's GPU would have rendered in the compact layout
+            idx = pkg.tiles.compact_pixel_index(w, h, rank, world, outside=-1)
+            inside = idx >= 0
+            gather.mine[k].zero_()
+            gather.mine[k][: idx.numel()][inside] = truth.view(-1, 3)[idx[inside]]
+            frame = gather(k)
+            if rank == 0:
+                ok = ok and bool(torch.equal(frame, truth))
         if rank == 0:
-            out.put(bool(torch.equal(frame, truth)))
+            out.put(ok)
         dist.barrier()
     finally:
         dist.destroy_process_group()
