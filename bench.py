@@ -212,7 +212,11 @@ def main():
         res = ref.render(jobs=cores, xstep=s, ystep=s)
         cpu_s = time.perf_counter() - c0
         cpu_rays = sum(res["counts"])
+        c1 = time.perf_counter()
+        res1 = ref.render(jobs=1, xstep=2 * s, ystep=2 * s)
+        cpu1_s = time.perf_counter() - c1
         cpu_baseline = {"value": cpu_rays / cpu_s, "unit": "rays/s", "cores": cores, "kind": "port",
+                        "single_core_value": sum(res1["counts"]) / cpu1_s,
                         "sample": "C++ restatement of the reference algorithm (group box gate + linear scan of all %d "
                                   "triangles per ray), -j %d, every %dth pixel of every %dth row of the same %dx%d frame: "
                                   "%d rays in %.2f s" % (info["triangles"], cores, s, s, W, H, cpu_rays, cpu_s)}

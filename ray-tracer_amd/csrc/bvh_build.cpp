@@ -18,7 +18,7 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 const int MAX_TRI_LEAF = env_int("RT_AMD_TRI_LEAF", 4);     // experiment knobs
-const int MAX_QUAD_LEAF = env_int("RT_AMD_QUAD_LEAF", 2);
+const int MAX_QUAD_LEAF = env_int("RT_AMD_QUAD_LEAF", 4);
 constexpr int SOFT_DEPTH = 36;  // beyond this, split at the median so depth stays bounded
 
 const double INF = std::numeric_limits<double>::infinity();

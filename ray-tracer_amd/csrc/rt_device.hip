@@ -131,17 +131,6 @@ DEV void check_cube_axis(double origin, double direction, double& tmin, double& 
 DEV int intersect_quadric(int type_flags, int closed, double minimum, double maximum, const Ray& r, double t[4]) {
   int n = 0;
   const int type = type_flags & QUAD_TYPE_MASK;
-  if (type == RT_SPHERE) {  // 839-866
-    double a = dot(r.d, r.d);
-    double b = 2.0 * dot(r.d, r.o);
-    double c = dot(r.o, r.o) - 1.0;
-    double disc = b * b - (4.0 * a * c);
-    if (disc < 0.0) return 0;
-    double sq = sqrt(disc);
-    t[0] = (-b - sq) / (2.0 * a);
-    t[1] = (-b + sq) / (2.0 * a);
-    return 2;
-  }
   if (type == RT_PLANE) {  // 891-908
     if (fabs(r.d.y) <= FEQ_EPSILON) return 0;
     t[0] = -r.o.y / r.d.y;
@@ -159,44 +148,47 @@ DEV int intersect_quadric(int type_flags, int closed, double minimum, double max
     t[1] = tmax;
     return 2;
   }
-  if (type == RT_CYLINDER || type == RT_CONE) {
-    const bool cone = type == RT_CONE;
-    double a, b, c;
-    if (!cone) {  // 987-1001
-      a = r.d.x * r.d.x + r.d.z * r.d.z;
-      b = 2.0 * r.o.x * r.d.x + 2.0 * r.o.z * r.d.z;
-      c = r.o.x * r.o.x + r.o.z * r.o.z - 1.0;
-    } else {  // 1077-1087
-      a = r.d.x * r.d.x - r.d.y * r.d.y + r.d.z * r.d.z;
-      b = 2.0 * r.o.x * r.d.x - 2.0 * r.o.y * r.d.y + 2.0 * r.o.z * r.d.z;
-      c = r.o.x * r.o.x - r.o.y * r.o.y + r.o.z * r.o.z;
-    }
+  if (type == RT_SPHERE || type == RT_CYLINDER || type == RT_CONE) {
+    // One quadratic a t^2 + b t + c = 0 for the three shapes (839-866, 981-1040, 1071-1144), so that
+    // the lanes of a wave holding different shapes share the square root and the two divisions.
+    // The y terms enter with the sign sy = +1 (sphere), 0 (cylinder), -1 (cone); multiplying by
+    // +-1 or 0 and doubling are exact, so every shape still sees its own operations in its own order:
+    //   sphere   a = dot(d, d)             b = 2 dot(d, o)                 c = dot(o, o) - 1
+    //   cylinder a = dx^2 + dz^2           b = 2 ox dx + 2 oz dz           c = ox^2 + oz^2 - 1
+    //   cone     a = dx^2 - dy^2 + dz^2    b = 2 ox dx - 2 oy dy + 2 oz dz c = ox^2 - oy^2 + oz^2
+    const bool sphere = type == RT_SPHERE, cone = type == RT_CONE;
+    const double sy = sphere ? 1.0 : (cone ? -1.0 : 0.0);
+    const double a = (r.d.x * r.d.x + sy * (r.d.y * r.d.y)) + r.d.z * r.d.z;
+    const double b = 2.0 * ((r.o.x * r.d.x + sy * (r.o.y * r.d.y)) + r.o.z * r.d.z);
+    const double c = ((r.o.x * r.o.x + sy * (r.o.y * r.o.y)) + r.o.z * r.o.z) - (cone ? 0.0 : 1.0);
     // Cylinder caps exist when closed; cone caps when NOT closed (1396 vs 1431).
-    const bool caps = (cone ? !closed : (closed != 0)) && !(fabs(r.d.y) < FEQ_EPSILON);
+    const bool caps = !sphere && (cone ? !closed : (closed != 0)) && !(fabs(r.d.y) < FEQ_EPSILON);
     bool walls = true;
-    if (!cone) {
-      if (a < FEQ_EPSILON) walls = false;  // 990-994: caps only
-    } else if (fabs(a) < FEQ_EPSILON) {    // 1089-1103: caps first, then the single root
-      if (type_flags & QUAD_SKIP_PARALLEL) return 0;
-      walls = false;
-    } else if (type_flags & QUAD_ONLY_PARALLEL) {
-      return 0;
+    if (cone) {
+      if (fabs(a) < FEQ_EPSILON) {  // 1089-1103: caps first, then the single root
+        if (type_flags & QUAD_SKIP_PARALLEL) return 0;
+        walls = false;
+      } else if (type_flags & QUAD_ONLY_PARALLEL) {
+        return 0;
+      }
+    } else if (!sphere && a < FEQ_EPSILON) {
+      walls = false;  // 990-994: caps only
     }
     if (walls) {
       double disc = b * b - 4.0 * a * c;
-      if (disc < 0.0) return 0;  // 1004-1006 / 1108-1110: no caps either
+      if (disc < 0.0) return 0;  // 848-850 / 1004-1006 / 1108-1110: no caps either
       double sq = sqrt(disc);
       double t0 = (-b - sq) / (2.0 * a);
       double t1 = (-b + sq) / (2.0 * a);
-      if (t0 > t1) {
+      if (!sphere && t0 > t1) {
         double s = t0;
         t0 = t1;
         t1 = s;
       }
       double y0 = r.o.y + t0 * r.d.y;
-      if (minimum < y0 && y0 < maximum) t[n++] = t0;
+      if (sphere || (minimum < y0 && y0 < maximum)) t[n++] = t0;
       double y1 = r.o.y + t1 * r.d.y;
-      if (minimum < y1 && y1 < maximum) t[n++] = t1;
+      if (sphere || (minimum < y1 && y1 < maximum)) t[n++] = t1;
     }
     if (caps) {  // 1388-1455
       double tl = (minimum - r.o.y) / r.d.y;

@@ -31,6 +31,17 @@ def test_shipped_scene_against_golden(pkg, name):
     check(out, st, g, w * h)
 
 
+@pytest.mark.parametrize("name", ["heightfield", "primitives"])
+def test_synthetic_configuration_against_golden(pkg, name, tmp_path):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_golden
+    g = np.load(os.path.join(GOLDEN, "synthetic_%s.npz" % name))
+    s = pkg.Scene.from_file(make_golden.synthetic_scene(name, str(tmp_path)), base_dir=ROOT, device=0)
+    out, st = s.render()
+    check(out, st, g, out["hit_leaf"].size)
+
+
 def test_every_primitive_pattern_and_group_against_golden(pkg):
     g = np.load(os.path.join(GOLDEN, "allprims.npz"))
     with open(os.path.join(GOLDEN, "allprims.json")) as f:

@@ -31,6 +31,21 @@ def test_scene_matches_golden(name):
     assert r["counts"] == [int(c) for c in g["counts"]]
 
 
+@pytest.mark.parametrize("name", ["heightfield", "primitives"])
+def test_synthetic_generators_match_golden(name, tmp_path):
+    """The seeded generators of the two synthetic configurations are deterministic: a tiny instance
+    regenerated here renders to the committed fixture."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_golden
+    g = np.load(os.path.join(GOLDEN, "synthetic_%s.npz" % name))
+    s = orc.OracleScene.from_file(make_golden.synthetic_scene(name, str(tmp_path)), base_dir=ROOT)
+    r = s.render(jobs=4)
+    assert np.array_equal(r["hit_leaf"], g["hit_leaf"])
+    assert np.array_equal(r["rgb64"], g["rgb64"])
+    assert r["counts"] == [int(c) for c in g["counts"]]
+
+
 def test_allprims_matches_golden():
     g = np.load(os.path.join(GOLDEN, "allprims.npz"))
     with open(os.path.join(GOLDEN, "allprims.json")) as f:
