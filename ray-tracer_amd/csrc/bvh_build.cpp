@@ -18,7 +18,7 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 const int MAX_TRI_LEAF = env_int("RT_AMD_TRI_LEAF", 4);     // experiment knobs
-const int MAX_QUAD_LEAF = env_int("RT_AMD_QUAD_LEAF", 4);
+const int MAX_QUAD_LEAF = env_int("RT_AMD_QUAD_LEAF", 2);
 constexpr int SOFT_DEPTH = 36;  // beyond this, split at the median so depth stays bounded
 
 const double INF = std::numeric_limits<double>::infinity();
@@ -244,7 +244,7 @@ uint32_t BvhBuilder::collapse(uint32_t bin_ref, int* need) {
       out.plane[a][1][c] = c < n ? round_up(slots[c].hi[a]) : -INFINITY;
     }
     out.child[c] = c < n ? refs[c] : REF_NONE;
-    out.pad[c] = 0;
+    out.alt[c] = c < n ? alt(refs[c]) : REF_NONE;
   }
   return make_ref(KIND_INNER, idx);
 }

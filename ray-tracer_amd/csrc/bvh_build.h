@@ -23,6 +23,14 @@ struct BvhBuilder {
   std::vector<uint32_t> quad_order;  // same for QuadPrim slots
   int stack_need = 0;                // traversal stack entries the last build()'s subtree can need
   std::vector<int> gate_need;        // the same for the subtree behind each gate (indexed by gate)
+  // What a ray that may skip the exact gate test walks instead of gate g: the subtree behind it (with
+  // skippable gates at its root resolved the same way), or the gate itself when it cannot be skipped.
+  std::vector<uint32_t> gate_alt;
+  uint32_t alt(uint32_t ref) const {
+    if (ref != REF_NONE && (ref >> 30) == KIND_GATE && (ref & 0x3FFFFFFFu) < gate_alt.size())
+      return gate_alt[ref & 0x3FFFFFFFu];
+    return ref;
+  }
 
   // Builds a subtree over items (reordered in place).  Returns its traversal
   // reference and the union box; REF_NONE when items is empty.

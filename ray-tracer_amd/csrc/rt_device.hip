@@ -102,7 +102,20 @@ DEV Ray transform_ray(const double* m, const Ray& r) {  // src/ray.rs:50-55
 
 struct Counters {
   unsigned long long node_visits, tri_tests, quad_tests, gate_tests;
+#ifdef RT_STAMPS
+  unsigned long long* sink;  // four sums: unbounded + setup, node loop, triangle runs, quadric runs + gates
+  unsigned long long tt;
+#endif
 };
+#ifdef RT_STAMPS
+#define RT_TBEGIN(c) (c).tt = __builtin_amdgcn_s_memtime()
+#define RT_TSTAMP(c, k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    if ((c).sink && (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd((c).sink + (k), now_ - (c).tt); \
+    (c).tt = now_; } while (0)
+#else
+#define RT_TBEGIN(c) do { } while (0)
+#define RT_TSTAMP(c, k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // primitive intersection, reference src/shape.rs:839-1455
@@ -448,8 +461,19 @@ DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& 
     for (int g = q.gate; g >= 0; g = S.gates[g].parent)
       if (!gate_passes(S.gates[g], ray)) return;
   }
-  Ray local = transform_ray(q.m, ray);  // src/shape.rs:1468
   double t[4];
+#ifndef RT_NO_PLANE_FAST
+  if (q.type == RT_PLANE) {
+    // only the y row of the transformed ray enters intersect_plane (src/shape.rs:891-908)
+    const double oy = q.m[4] * ray.o.x + q.m[5] * ray.o.y + q.m[6] * ray.o.z + q.m[7];
+    const double dy = q.m[4] * ray.d.x + q.m[5] * ray.d.y + q.m[6] * ray.d.z;
+    if (fabs(dy) <= FEQ_EPSILON) return;
+    t[0] = -oy / dy;
+    Q.leaf_ts(q.leaf, 1, t);
+    return;
+  }
+#endif
+  Ray local = transform_ray(q.m, ray);  // src/shape.rs:1468
   int n = intersect_quadric(q.type, q.closed, q.minimum, q.maximum, local, t);
   if (n) Q.leaf_ts(q.leaf, n, t);
 }
@@ -460,6 +484,7 @@ DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& 
 // only when all lanes of the wave have reached a primitive run or a gate is that work done.
 template <class Query, class Stack, bool COUNT>
 DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counters& cnt) {
+  RT_TBEGIN(cnt);
   for (int i = 0; i < S.n_unbounded; i++) {
     if (COUNT) cnt.quad_tests++;
     test_quad(S, S.unbounded[i], ray, Q, true);
@@ -500,7 +525,11 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
   float qhi = Q.hi_f();
   const char* nodes = reinterpret_cast<const char*>(S.nodes);
   st.clear();
-  uint32_t cur = S.root;
+  // rays without a near-zero direction component read the child references in which skippable
+  // gates are already replaced by their subtrees
+  const uint32_t child_off = rb.tiny ? 96u : 112u;
+  uint32_t cur = rb.tiny ? S.root : S.root_alt;
+  RT_TSTAMP(cnt, 0);
   while (cur != REF_NONE) {
     while ((cur >> 30) == KIND_INNER) {
       const uint32_t nd = cur << 7;  // byte offset of the node (inner kind bits are zero)
@@ -509,7 +538,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
          nz = load_f4(nodes, nd + rb.off_near[2]);
       F4 fx = load_f4(nodes, nd + (rb.off_near[0] ^ 16u)), fy = load_f4(nodes, nd + (rb.off_near[1] ^ 16u)),
          fz = load_f4(nodes, nd + (rb.off_near[2] ^ 16u));
-      uint4 ch = *reinterpret_cast<const uint4*>(nodes + nd + 96u);
+      uint4 ch = *reinterpret_cast<const uint4*>(nodes + nd + child_off);
       uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
       float tn[4];
 #pragma unroll
@@ -538,6 +567,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       st.push_if(o3, o3 != REF_NONE);
       cur = bc != REF_NONE ? bc : st.pop_or_none();
     }
+    RT_TSTAMP(cnt, 1);
     if (cur == REF_NONE) break;
     const uint32_t kind = cur >> 30;
     if (kind == KIND_GATE) {
@@ -550,6 +580,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
         pass = gate_passes(g, ray);
       }
       cur = pass ? g.root : st.pop_or_none();
+      RT_TSTAMP(cnt, 3);
       continue;
     }
     const uint32_t first = cur & MAX_RUN_FIRST, count = ((cur >> 27) & 7u) + 1u;
@@ -567,11 +598,13 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
         }
         if (hit) Q.leaf_tri(tr.leaf, t, u, v);
       }
+      RT_TSTAMP(cnt, 2);
     } else {
       for (uint32_t i = 0; i < count; i++) {
         if (COUNT) cnt.quad_tests++;
         test_quad(S, S.quads[first + i], ray, Q, false);
       }
+      RT_TSTAMP(cnt, 3);
     }
     if (Q.done()) return;
     qhi = Q.hi_f();
@@ -625,7 +658,19 @@ DEV uint32_t thread_in_block() { return BLOCK == 64 ? (uint32_t)__lane_id() : th
 // adds do not all land on one address.
 constexpr int STAT_SLOTS = 64;
 constexpr int STAT_RAYS = 8;
-constexpr int STAT_WORDS = STAT_RAYS + 3 * STAT_SLOTS;
+#ifdef RT_STAMPS
+// Diagnostic build: per-wave clock stamps between the sections of k_generation, summed per section.
+constexpr int STAMP_WORDS = 16;
+#else
+constexpr int STAMP_WORDS = 0;
+#endif
+constexpr int STAT_WORDS = STAT_RAYS + 3 * STAT_SLOTS + STAMP_WORDS;
+#ifdef RT_STAMPS
+#define RT_STAMP(k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    if ((thread_in_block() & 63) == 0) atomicAdd(&stats[STAT_RAYS + 3 * STAT_SLOTS + (k)], now_ - stamp_); stamp_ = now_; } while (0)
+#else
+#define RT_STAMP(k) do { } while (0)
+#endif
 
 // Ray index -> pixel: tile k of this part, then 8x8 pixel blocks per wave so the
 // 64 rays of a wave stay close in screen space.
@@ -863,6 +908,9 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
   __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
   LdsStack<STACK, BLOCK> st;
   st.init(lds);
+#ifdef RT_STAMPS
+  unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
   const uint32_t i = blockIdx.x * BLOCK + thread_in_block();
   bool active = i < n;
   uint32_t px = 0, py = 0;
@@ -874,10 +922,16 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     ray = load_ray(g, i);
   }
 
-  Counters ct = {0, 0, 0, 0}, cs = {0, 0, 0, 0};
+  Counters ct{}, cs{};
+#ifdef RT_STAMPS
+  ct.sink = stats + STAT_RAYS + 3 * STAT_SLOTS + 8;
+  cs.sink = stats + STAT_RAYS + 3 * STAT_SLOTS + 12;
+#endif
   ClosestQuery Q;
   Q.init();
+  RT_STAMP(0);  // ray generation
   if (active) traverse<ClosestQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, Q, st, ct);
+  RT_STAMP(1);  // closest-hit traversal
   const bool hit = active && Q.best_leaf != 0x7FFFFFFF;
   const int leaf = hit ? Q.best_leaf : -1;
 
@@ -1025,6 +1079,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
 
   // World::is_shadowed (src/world.rs:123-137), then the in_shadow branch of lighting
   double out_r = 0.0, out_g = 0.0, out_b = 0.0;  // World::color_at: no hit => black
+  RT_STAMP(2);  // shading, spawning
   if (hit) {
     V3 lightpos = v3(S.light_position[0], S.light_position[1], S.light_position[2]);
     V3 v = lightpos - over_point;
@@ -1037,6 +1092,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     out_g = SQ.found ? ag : lg;
     out_b = SQ.found ? ab : lb;
   }
+  RT_STAMP(3);  // shadow traversal
   if (MODE == 0) {
     write_pixel(img, cam.hsize, px, py, i, active, out_r, out_g, out_b, leaf);
   } else if (i < n) {
@@ -1055,6 +1111,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     flush_counters(ct, stats);
     flush_counters(cs, stats + 4);
   }
+  RT_STAMP(4);  // output
 }
 
 // shade_hit's final expression (src/world.rs:236-245), children first.
@@ -1120,7 +1177,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect(SceneDev S, GenView g, uint
   if (i >= n) return;
   LdsStack<STACK, BLOCK> st;
   st.init(lds);
-  Counters cnt = {0, 0, 0, 0};
+  Counters cnt{};
   ClosestQuery Q;
   Q.init();
   traverse<ClosestQuery, LdsStack<STACK, BLOCK>, false>(S, load_ray(g, i), Q, st, cnt);
@@ -1137,7 +1194,7 @@ __global__ void __launch_bounds__(BLOCK) k_points_shadowed(SceneDev S, uint32_t 
   if (i >= n) return;
   LdsStack<STACK, BLOCK> st;
   st.init(lds);
-  Counters cnt = {0, 0, 0, 0};
+  Counters cnt{};
   V3 p = v3(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]);
   V3 v = v3(S.light_position[0], S.light_position[1], S.light_position[2]) - p;
   ShadowQuery Q;
@@ -1441,6 +1498,8 @@ struct SceneBuild {
       if (!(G.bmin[a] <= lo[a] + tol) || !(G.bmax[a] >= hi[a] - tol)) contains = false;
     }
     g.skippable = (contains && is_identity(G.to_local)) ? 1u : 0u;
+    if ((size_t)gi >= bvh.gate_alt.size()) bvh.gate_alt.resize(gi + 1, REF_NONE);
+    bvh.gate_alt[gi] = g.skippable ? bvh.alt(g.root) : make_ref(KIND_GATE, (uint32_t)gi);
     *has_item = g.root != REF_NONE;
     if (*has_item) {
       out_item->kind = KIND_GATE;
@@ -1654,6 +1713,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((rc = upload(s, mats, &s->dev.materials))) return rc;
   if ((rc = upload(s, pats, &s->dev.patterns))) return rc;
   s->dev.root = root;
+  s->dev.root_alt = b.bvh.alt(root);
   s->dev.n_unbounded = (int32_t)b.unbounded.size();
   s->dev.n_leaves = d->n_leaves;
   for (int a = 0; a < 3; a++) {
@@ -1895,6 +1955,17 @@ int collect_frame(rt_scene* s, rt_scene::FrameSlot& f) {
   if (!f.pending) return RT_OK;
   HIP_TRY(hipEventSynchronize(f.done));
   f.pending = false;
+#ifdef RT_STAMPS
+  {
+    const unsigned long long* t = f.h_stats + STAT_RAYS + 3 * STAT_SLOTS;
+    double sum = 0;
+    for (int k = 0; k < 5; k++) sum += (double)t[k];
+    fprintf(stderr, "[rt_amd] wave clock shares: raygen %.3f closest %.3f shade %.3f shadow %.3f output %.3f (total %.3g ticks)\n",
+            t[0] / sum, t[1] / sum, t[2] / sum, t[3] / sum, t[4] / sum, sum);
+    fprintf(stderr, "[rt_amd]   closest: setup %.3f nodes %.3f tris %.3f quads/gates %.3f | shadow: setup %.3f nodes %.3f tris %.3f quads/gates %.3f\n",
+            t[8] / sum, t[9] / sum, t[10] / sum, t[11] / sum, t[12] / sum, t[13] / sum, t[14] / sum, t[15] / sum);
+  }
+#endif
   rt_stats one{};
   decode_stats(f.h_stats, &one);
   float ms = 0;

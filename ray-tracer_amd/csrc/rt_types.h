@@ -31,11 +31,13 @@ inline uint32_t make_run(uint32_t kind, uint32_t first, uint32_t count) {
 // plane[a][k][c] is the lower (k = 0) or upper (k = 1) plane of axis a of child c: a ray picks the
 // near plane of an axis by byte offset (32 a + 0 or 16), the far plane is that offset ^ 16, and one
 // 16-byte load brings the plane of all four children.  Empty slots hold an inverted box
-// (+inf, -inf) and REF_NONE.
+// (+inf, -inf) and REF_NONE.  alt[] repeats child[] with every skippable gate replaced by the
+// subtree behind it: a ray that may skip those gates (Gate::skippable) reads alt[] and never leaves
+// the node loop for them.
 struct alignas(128) BvhNode {
   float plane[3][2][4];
   uint32_t child[4];
-  uint32_t pad[4];
+  uint32_t alt[4];
 };
 static_assert(sizeof(BvhNode) == 128, "BvhNode must be one cache line");
 
@@ -135,12 +137,12 @@ struct SceneDev {
   const TriShade* tri_shade;
   const MaterialDev* materials;
   const PatternDev* patterns;
-  uint32_t root;
+  uint32_t root;      // for rays that take every gate test
+  uint32_t root_alt;  // for rays that may skip skippable gates
   int32_t n_unbounded;
   int32_t n_leaves;
   int32_t n_bands;
   int32_t band_grid_n;
-  int32_t pad;
   double light_intensity[3];
   double light_position[3];
 };
