@@ -18,7 +18,7 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 const int MAX_TRI_LEAF = env_int("RT_AMD_TRI_LEAF", 4);     // experiment knobs
-const int MAX_QUAD_LEAF = env_int("RT_AMD_QUAD_LEAF", 2);
+const int MAX_QUAD_LEAF = env_int("RT_AMD_QUAD_LEAF", 4);
 constexpr int SOFT_DEPTH = 36;  // beyond this, split at the median so depth stays bounded
 
 const double INF = std::numeric_limits<double>::infinity();
@@ -43,6 +43,16 @@ inline void centroid(const BuildItem& it, double c[3]) {
   for (int a = 0; a < 3; a++) c[a] = 0.5 * (it.lo[a] + it.hi[a]);
 }
 
+double env_double(const char* name, double dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atof(v) : dflt;
+}
+// Cost of visiting one more node relative to one primitive test; < 0 turns the cost test off
+// (every range that fits a run becomes a leaf).
+const double SAH_NODE_TRI = env_double("RT_AMD_SAH_NODE_TRI", -1.0);
+const double SAH_NODE_QUAD = env_double("RT_AMD_SAH_NODE_QUAD", 1.5);
+
+// Can the range be one primitive run at all?
 bool leaf_ok(const BuildItem* items, size_t n) {
   if (n == 1) return true;
   uint32_t k = items[0].kind;
@@ -75,7 +85,9 @@ uint32_t BvhBuilder::build_range(BuildItem* items, size_t n, int depth, double l
     lo[a] = box.lo[a];
     hi[a] = box.hi[a];
   }
-  if (leaf_ok(items, n)) return make_leaf(items, n);
+  const bool may_leaf = leaf_ok(items, n);
+  const double node_cost = may_leaf && n > 1 ? (items[0].kind == KIND_TRI ? SAH_NODE_TRI : SAH_NODE_QUAD) : -1.0;
+  if (may_leaf && (n == 1 || node_cost < 0.0)) return make_leaf(items, n);
 
   size_t mid = 0;
   bool split = false;
@@ -118,6 +130,9 @@ uint32_t BvhBuilder::build_range(BuildItem* items, size_t n, int depth, double l
         }
       }
     }
+    // surface-area heuristic: splitting pays when the expected tests of the two halves plus the
+    // extra node cost less than testing all n primitives
+    if (may_leaf && !(best_cost + node_cost * box.half_area() < (double)n * box.half_area())) return make_leaf(items, n);
     if (best_axis >= 0) {
       int a = best_axis;
       double scale = BINS / (cbox.hi[a] - cbox.lo[a]);
@@ -131,6 +146,7 @@ uint32_t BvhBuilder::build_range(BuildItem* items, size_t n, int depth, double l
       split = mid > 0 && mid < n;
     }
   }
+  if (!split && may_leaf) return make_leaf(items, n);
   if (!split) {
     int a = 0;
     double ext = -1;

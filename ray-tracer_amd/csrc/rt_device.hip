@@ -1512,8 +1512,10 @@ struct SceneBuild {
   }
 };
 
+// 40 entries x 64 lanes x 4 B = 10 KB per wave: sixteen waves still fit the 160 KB of LDS of a CU,
+// so the stack does not limit occupancy; deeper scenes take the 64-entry kernels (10 waves per CU).
 #ifndef RT_STACK_SMALL
-#define RT_STACK_SMALL 32
+#define RT_STACK_SMALL 40
 #endif
 constexpr int STACK_SMALL = RT_STACK_SMALL;
 int pick_stack(int need) { return need <= STACK_SMALL ? STACK_SMALL : 64; }
