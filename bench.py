@@ -101,7 +101,7 @@ def main():
     gather = pkg.tiles.FrameGather(W, H, device, rank, world)
     frames = [torch.zeros((H, W, 3), dtype=torch.uint8, device=device) for _ in range(2)] if world == 1 else None
     host_frames = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)] if rank == 0 else None
-    copy_stream = torch.cuda.Stream(device=device)
+    copy_stream = torch.cuda.ExternalStream(scene.copy_stream_ptr(), device=device)  # the library's copy stream
     buffer_free = [torch.cuda.Event() for _ in range(2)]
     render_stream = torch.cuda.ExternalStream(scene.stream_ptr(), device=device)  # the library's own stream
     step_no = [0]
@@ -115,16 +115,17 @@ def main():
         if world == 1:
             frame = frames[k]
             scene.render_device(rgb8_ptr=frame.data_ptr(), wait=False)
-            torch.cuda.current_stream().wait_stream(render_stream)
+            scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel())  # framebuffer on the host
+            buffer_free[k].record(copy_stream)
+            return
         else:
             scene.render_device(rgb8_ptr=gather.mine[k].data_ptr(), part=rank, n_parts=world, wait=False, compact=True)
             torch.cuda.current_stream().wait_stream(render_stream)
             frame = gather(k)  # rank 0: the whole frame
         if rank == 0:
-            copy_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(copy_stream):
-                host_frames[k].copy_(frame, non_blocking=True)  # framebuffer on the host
-                buffer_free[k].record()
+            scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel(),
+                           after_stream=torch.cuda.current_stream().cuda_stream)
+            buffer_free[k].record(copy_stream)
         else:
             buffer_free[k].record()
 

@@ -211,6 +211,14 @@ int rt_scene_wait(rt_scene* scene, rt_stats* total);
  * buffer to be free. */
 int rt_scene_stream(rt_scene* scene, void** hip_stream);
 
+/* Copies `bytes` from device memory to pinned (page-locked) host memory on the scene's copy
+ * stream (a DMA transfer that runs beside the next frame's kernel).  The copy is enqueued; it starts after everything enqueued so far on after_stream (a hipStream_t; NULL = the
+ * scene's render stream) and is complete after rt_scene_wait or after the copy stream
+ * (rt_scene_copy_stream) has drained.  The caller keeps src_dev and dst_host untouched until then.
+ * Replaces the per-pixel channel receive of the reference's canvas (src/parallel.rs:196-200). */
+int rt_download(rt_scene* scene, const void* src_dev, void* dst_host, uint64_t bytes, void* after_stream);
+int rt_scene_copy_stream(rt_scene* scene, void** hip_stream);
+
 /* Same, into host buffers (the library stages through device memory). */
 int rt_render_host(rt_scene* scene, const rt_camera* camera, int part, int n_parts, uint32_t flags,
                    uint8_t* rgb8, double* rgb64, int32_t* hit_leaf, rt_stats* stats);

@@ -89,6 +89,8 @@ def libraries():
     amd.rt_render.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
     amd.rt_scene_wait.argtypes = [vp, C.POINTER(RtStats)]
     amd.rt_scene_stream.argtypes = [vp, C.POINTER(vp)]
+    amd.rt_scene_copy_stream.argtypes = [vp, C.POINTER(vp)]
+    amd.rt_download.argtypes = [vp, vp, vp, u64, vp]
     amd.rt_render_host.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
     amd.rt_ray_for_pixel.argtypes = [vp, C.POINTER(RtCamera), u64, vp, vp]
     amd.rt_color_at.argtypes = [vp, u64, vp, i32, u32, vp, vp, C.POINTER(RtStats)]
@@ -254,6 +256,17 @@ class Scene:
         st = RtStats()
         self._check(self._amd.rt_scene_wait(self._dev(), C.byref(st)))
         return st
+
+    def download(self, src_ptr, dst_ptr, nbytes, after_stream=0):
+        """rt_download: device -> pinned host copy, enqueued on the scene's copy stream after the work
+        now on after_stream (address of a hipStream_t; 0 = the scene's render stream)."""
+        self._check(self._amd.rt_download(self._dev(), C.c_void_p(src_ptr), C.c_void_p(dst_ptr), nbytes,
+                                          C.c_void_p(after_stream or None)))
+
+    def copy_stream_ptr(self):
+        p = C.c_void_p()
+        self._check(self._amd.rt_scene_copy_stream(self._dev(), C.byref(p)))
+        return p.value or 0
 
     def stream_ptr(self):
         """Address of the hipStream_t the scene's work runs on (for torch.cuda.ExternalStream)."""

@@ -177,3 +177,27 @@ def test_compact_parts_rebuild_the_frame(pkg, root, size, n_parts):
     assert np.array_equal(canvas[:-1].view(h, w, 3).cpu().numpy(), want["rgb8"])
     with pytest.raises(pkg.RtError):
         gpu.render_device(rgb64_ptr=canvas.data_ptr(), compact=True)  # the compact layout is rgb8 only
+
+
+def test_download_copies_frames_to_pinned_memory(pkg, root):
+    """rt_download after an enqueued frame: the pinned host buffer holds the frame once rt_scene_wait
+    returns; sizes with a tail and unaligned buffers take the same contents across."""
+    import torch
+
+    gpu, _ = load_pair(pkg, root, "teapot", (200, 112))
+    want, _ = gpu.render(rgb64=False, hit_leaf=False)
+    dev = torch.zeros((112, 200, 3), dtype=torch.uint8, device="cuda:0")
+    host = torch.zeros((112, 200, 3), dtype=torch.uint8).pin_memory()
+    gpu.render_device(rgb8_ptr=dev.data_ptr(), wait=False)
+    gpu.download(dev.data_ptr(), host.data_ptr(), dev.numel())
+    gpu.wait()
+    assert np.array_equal(host.numpy(), want["rgb8"])
+    src = torch.arange(100003, dtype=torch.int32, device="cuda:0").to(torch.uint8)
+    for offset, n in [(0, 100003), (0, 7), (16, 4096), (3, 1000)]:  # tail bytes; tiny; aligned; unaligned fallback
+        dst = torch.zeros(100003, dtype=torch.uint8).pin_memory()
+        torch.cuda.synchronize()
+        gpu.download(src.data_ptr() + offset, dst.data_ptr() + offset, n,
+                     after_stream=torch.cuda.current_stream().cuda_stream)
+        gpu.wait()
+        assert torch.equal(dst[offset:offset + n], src[offset:offset + n].cpu())
+        assert int(dst[offset + n:].sum()) == 0 and int(dst[:offset].sum()) == 0
