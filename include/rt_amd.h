@@ -30,7 +30,7 @@ extern "C" {
 typedef enum rt_status {
   RT_OK = 0,
   RT_ERR_INVALID = -1,     /* bad argument or inconsistent description */
-  RT_ERR_UNSUPPORTED = -2, /* valid for the reference, not built here (CSG, projective transforms) */
+  RT_ERR_UNSUPPORTED = -2, /* valid for the reference, not built here (projective transforms, CSG over many shapes) */
   RT_ERR_DEVICE = -3,      /* HIP runtime failure */
   RT_ERR_NOMEM = -4
 } rt_status;
@@ -85,6 +85,9 @@ typedef struct rt_leaf {
   int32_t xform;    /* index into xforms */
   int32_t gate;     /* innermost enclosing group, index into gates, -1 at top level */
   int32_t tri;      /* index into triangles for the two triangle types, else -1 */
+  int32_t csg;      /* innermost enclosing CSG operator, index into csg, -1 when there is none */
+  uint32_t csg_left; /* bit k: `left.includes(shape)` (src/shape.rs:450-467, by value) for the k-th
+                        enclosing operator counted from the innermost one */
   double minimum, maximum; /* cylinder / cone extent along y */
   double plane_normal[3];  /* `ShapeType::Plane(n)` */
 } rt_leaf;
@@ -95,10 +98,24 @@ typedef struct rt_leaf {
  * in the group's local space. */
 typedef struct rt_gate {
   int32_t parent;      /* enclosing group or -1 */
-  int32_t reserved;
+  int32_t csg;         /* innermost CSG operator the group lies below, or -1 */
   double to_local[16]; /* world -> group space for rays (product of local inverses) */
   double bmin[3], bmax[3];
 } rt_gate;
+
+/* One `ShapeType::Union / Intersection / Difference` (src/shape.rs:319-364).  Its operands are the
+ * shapes below it; the leaves below one operator are contiguous in leaves[] (depth-first order).
+ * Operators are listed parents first.  intersect_csg and filter_intersections
+ * (src/shape.rs:1339-1354, src/intersect.rs:278-328) run per ray on the device. */
+typedef enum rt_csg_op { RT_CSG_UNION = 0, RT_CSG_INTERSECTION = 1, RT_CSG_DIFFERENCE = 2 } rt_csg_op;
+typedef struct rt_csg {
+  int32_t op;         /* rt_csg_op */
+  int32_t parent;     /* enclosing operator (directly or through groups) or -1 */
+  int32_t gate;       /* innermost group enclosing the operator itself, or -1 */
+  int32_t first_leaf; /* leaves[first_leaf .. first_leaf + n_leaves) lie below this operator */
+  int32_t n_leaves;
+  int32_t reserved;
+} rt_csg;
 
 /* `Material` (src/light.rs:34-63). */
 typedef struct rt_material {
@@ -137,6 +154,8 @@ typedef struct rt_camera {
 typedef struct rt_scene_desc {
   rt_light light;
   int32_t n_leaves, n_gates, n_xforms, n_triangles, n_materials, n_patterns;
+  int32_t n_csg, reserved;
+  const rt_csg* csg;
   const rt_leaf* leaves;
   const rt_gate* gates;
   const rt_xform* xforms;

@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -363,12 +364,17 @@ struct ContainerQuery {
 // Per-lane stack in LDS: entry e of thread t lives at stack[e * BLOCK + t], so
 // the 64 lanes of a wave hit 64 consecutive banks.
 #ifndef RT_PRIVATE_STACK
-template <int STACK, int BLOCK>
+template <int STACK, int BLOCK, bool CSG = false>
 struct LdsStack {
+  static constexpr bool WITH_CSG = CSG;  // the kernels built for scenes with CSG operators carry eval_csg
+  static constexpr int THREADS = BLOCK;
   uint32_t* base;
+  uint32_t* csg;  // this lane's column of the CSG hit list (dynamic LDS), or null when the scene has no CSG
   int sp;
-  DEV void init(uint32_t* lds) {
-    base = lds + (BLOCK == 64 ? (uint32_t)__lane_id() : threadIdx.x);
+  DEV void init(uint32_t* lds, uint32_t* csg_lds = nullptr) {
+    const uint32_t tid = BLOCK == 64 ? (uint32_t)__lane_id() : threadIdx.x;
+    base = lds + tid;
+    csg = csg_lds ? csg_lds + tid : nullptr;
     sp = 0;
   }
   DEV void push(uint32_t r) {
@@ -388,11 +394,17 @@ struct LdsStack {
 #define RT_STACK_LDS(n) (n)
 #else
 // Experiment: per-lane stack in private (scratch) memory instead of LDS.
-template <int STACK, int BLOCK>
+template <int STACK, int BLOCK, bool CSG = false>
 struct LdsStack {
+  static constexpr bool WITH_CSG = CSG;
+  static constexpr int THREADS = BLOCK;
   uint32_t slot[STACK];
+  uint32_t* csg;
   int sp;
-  DEV void init(uint32_t*) { sp = 0; }
+  DEV void init(uint32_t*, uint32_t* csg_lds = nullptr) {
+    csg = csg_lds ? csg_lds + threadIdx.x : nullptr;
+    sp = 0;
+  }
   DEV void push(uint32_t r) {
     if (sp < STACK) slot[sp++] = r;
   }
@@ -478,6 +490,107 @@ DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& 
   if (n) Q.leaf_ts(q.leaf, n, t);
 }
 
+// intersect_csg + filter_intersections (src/shape.rs:1339-1354, src/intersect.rs:278-328) for one
+// root operator tree.  The reference intersects both operands, sorts, and lets an intersection
+// through depending on which operand it came from and whether the ray is inside the other; nested
+// operators filter their own lists first.  Here all leaf intersections below the root go into one
+// list sorted by (t, leaf order) -- the order every stable sort of the reference yields -- and the
+// operators run innermost first over the entries that are theirs and still alive.
+// The list lives in LDS: entry e of a lane at words (3 e + {0, 1, 2}) * BLOCK: t low, t high, leaf slot.
+template <class Query, class Stack, int BLOCK_>
+DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query& Q, Stack& st, bool outer_gates) {
+  const CsgRoot R = S.csg_roots[root_index];
+  uint32_t* list = st.csg;
+  if (!list) return;
+  if (outer_gates)
+    for (int g = R.gate; g >= 0; g = S.gates[g].parent)
+      if (!gate_passes(S.gates[g], ray)) return;
+  auto put = [&](int e, double t, uint32_t who) {
+    list[(3 * e + 0) * BLOCK_] = (uint32_t)__double2loint(t);
+    list[(3 * e + 1) * BLOCK_] = (uint32_t)__double2hiint(t);
+    list[(3 * e + 2) * BLOCK_] = who;
+  };
+  auto get_t = [&](int e) { return __hiloint2double((int)list[(3 * e + 1) * BLOCK_], (int)list[(3 * e + 0) * BLOCK_]); };
+  auto get_who = [&](int e) { return list[(3 * e + 2) * BLOCK_]; };
+  int n = 0;
+  for (uint32_t j = 0; j < R.n_leaves; j++) {
+    const CsgLeaf L = S.csg_leaves[R.first_leaf + j];
+    bool open = true;
+    for (int g = L.gate; g != R.gate && g >= 0; g = S.gates[g].parent)  // groups between the root and the leaf
+      if (!gate_passes(S.gates[g], ray)) {
+        open = false;
+        break;
+      }
+    if (!open) continue;
+    double t[4];
+    int m = 0;
+    const uint32_t idx = L.ref & MAX_RUN_FIRST;
+    if ((L.ref >> 30) == KIND_TRI) {
+      const TriIsect& tr = S.tris[idx];
+      double u, v;
+      bool hit = tr.xform >= 0 ? intersect_triangle(tr, transform_ray(S.xforms[tr.xform].ray_inv, ray), t[0], u, v)
+                               : intersect_triangle(tr, ray, t[0], u, v);
+      m = hit ? 1 : 0;
+    } else {
+      const QuadPrim& q = S.quads[idx];
+      m = intersect_quadric(q.type, q.closed, q.minimum, q.maximum, transform_ray(q.m, ray), t);
+    }
+    for (int k = 0; k < m; k++) {
+      if (!(t[k] == t[k]) || n >= CSG_MAX_HITS) continue;  // NaN never orders (the reference's sort would panic)
+      int e = n;
+      while (e > 0 && get_t(e - 1) > t[k]) {  // stable: equal t stays behind earlier leaves
+        put(e, get_t(e - 1), get_who(e - 1));
+        e--;
+      }
+      put(e, t[k], j);
+      n++;
+    }
+  }
+  if (n == 0) return;
+  uint32_t alive = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+  for (int c = (int)R.n_nodes - 1; c >= 0; c--) {  // children carry larger indices than their parents
+    const int op = S.csg_nodes[R.first_node + c].op;
+    bool inl = false, inr = false;
+    for (int e = 0; e < n; e++) {
+      if (!((alive >> e) & 1u)) continue;
+      const CsgLeaf& L = S.csg_leaves[R.first_leaf + get_who(e)];
+      int a = L.node, level = 0;
+      while (a > c) {
+        a = S.csg_nodes[R.first_node + a].parent;
+        level++;
+      }
+      if (a != c) continue;  // not below this operator
+      const bool lhit = (L.left_mask >> level) & 1u;
+      bool allowed;  // intersection_allowed (src/intersect.rs:278-290)
+      if (op == RT_CSG_UNION) allowed = lhit ? !inr : !inl;
+      else if (op == RT_CSG_INTERSECTION) allowed = lhit ? inr : inl;
+      else allowed = lhit ? !inr : inl;
+      if (lhit) inl = !inl;
+      else inr = !inr;
+      if (!allowed) alive &= ~(1u << e);
+    }
+  }
+  if (!alive) return;
+  for (uint32_t j = 0; j < R.n_leaves; j++) {
+    double t[4];
+    int m = 0;
+    for (int e = 0; e < n; e++)
+      if (((alive >> e) & 1u) && get_who(e) == j && m < 4) t[m++] = get_t(e);
+    if (!m) continue;
+    const CsgLeaf L = S.csg_leaves[R.first_leaf + j];
+    const uint32_t idx = L.ref & MAX_RUN_FIRST;
+    if ((L.ref >> 30) == KIND_TRI) {
+      const TriIsect& tr = S.tris[idx];
+      double tt, u, v;  // again, for the barycentric coordinates of a smooth triangle
+      bool hit = tr.xform >= 0 ? intersect_triangle(tr, transform_ray(S.xforms[tr.xform].ray_inv, ray), tt, u, v)
+                               : intersect_triangle(tr, ray, tt, u, v);
+      if (hit) Q.leaf_tri(tr.leaf, tt, u, v);
+    } else {
+      Q.leaf_ts(S.quads[idx].leaf, m, t);
+    }
+  }
+}
+
 // World::intersect (src/world.rs:107-117) over the acceleration structure: first the primitives
 // without a finite box, then the 4-wide BVH.  While-while traversal: every lane first descends
 // inner nodes (the nearest hit child stays in a register, the others go on the LDS stack), and
@@ -489,6 +602,8 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     if (COUNT) cnt.quad_tests++;
     test_quad(S, S.unbounded[i], ray, Q, true);
   }
+  if constexpr (Stack::WITH_CSG)
+    for (int i = 0; i < S.n_csg_unbounded; i++) eval_csg<Query, Stack, Stack::THREADS>(S, S.csg_unbounded[i], ray, Q, st, true);
   if (S.n_bands > 0) {
     const double xx = ray.d.x * ray.d.x, yy = ray.d.y * ray.d.y, zz = ray.d.z * ray.d.z;
     const double xy = ray.d.x * ray.d.y, xz = ray.d.x * ray.d.z, yz = ray.d.y * ray.d.z;
@@ -572,6 +687,14 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     const uint32_t kind = cur >> 30;
     if (kind == KIND_GATE) {
       const Gate& g = S.gates[cur & 0x3FFFFFFFu];
+      if (g.csg) {
+        if constexpr (Stack::WITH_CSG) eval_csg<Query, Stack, Stack::THREADS>(S, g.csg - 1u, ray, Q, st, false);
+        if (Q.done()) break;
+        qhi = Q.hi_f();
+        cur = st.pop_or_none();
+        RT_TSTAMP(cnt, 3);
+        continue;
+      }
       bool pass;
       if (g.skippable && !rb.tiny) {
         pass = true;
@@ -900,14 +1023,15 @@ DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y
 #ifndef RT_MIN_WAVES_SPAWN
 #define RT_MIN_WAVES_SPAWN 3
 #endif
-template <int STACK, bool COUNT, int MODE>
+template <int STACK, bool COUNT, int MODE, bool CSG>
 __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES_SPAWN)
     k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_capacity, int remaining,
                  uint32_t* next_count, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
                  uint32_t tiles_x, ImageOut img) {
   __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
-  LdsStack<STACK, BLOCK> st;
-  st.init(lds);
+  LdsStack<STACK, BLOCK, CSG> st;
+  extern __shared__ uint32_t csg_lds[];  // CSG_MAX_HITS * 3 * BLOCK words when the scene has CSG operators, else nothing
+  st.init(lds, CSG ? csg_lds : nullptr);
 #ifdef RT_STAMPS
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -930,7 +1054,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
   ClosestQuery Q;
   Q.init();
   RT_STAMP(0);  // ray generation
-  if (active) traverse<ClosestQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, Q, st, ct);
+  if (active) traverse<ClosestQuery, LdsStack<STACK, BLOCK, CSG>, COUNT>(S, ray, Q, st, ct);
   RT_STAMP(1);  // closest-hit traversal
   const bool hit = active && Q.best_leaf != 0x7FFFFFFF;
   const int leaf = hit ? Q.best_leaf : -1;
@@ -999,7 +1123,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
       if (m.flags & 8) {  // n1 / n2 are consumed: refraction or Schlick (src/intersect.rs:191-234)
         ContainerQuery C;
         C.init(leaf);
-        traverse<ContainerQuery, LdsStack<STACK, BLOCK>, COUNT>(S, ray, C, st, ct);
+        traverse<ContainerQuery, LdsStack<STACK, BLOCK, CSG>, COUNT>(S, ray, C, st, ct);
         double ri_hit = m.refractive_index;
         double ri_other = C.other_leaf >= 0 ? S.materials[S.leaves[C.other_leaf].material].refractive_index : 1.0;
         if (C.hit_inside) {
@@ -1087,7 +1211,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     SQ.distance = magnitude(v);
     SQ.found = false;
     Ray shadow_ray{over_point, normalize(v)};
-    traverse<ShadowQuery, LdsStack<STACK, BLOCK>, COUNT>(S, shadow_ray, SQ, st, cs);
+    traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG>, COUNT>(S, shadow_ray, SQ, st, cs);
     out_r = SQ.found ? ar : lr;
     out_g = SQ.found ? ag : lg;
     out_b = SQ.found ? ab : lb;
@@ -1170,30 +1294,32 @@ __global__ void __launch_bounds__(BLOCK)
 }
 
 // World::intersect + Intersections::hit only (rt_intersect_hit).
-template <int STACK>
+template <int STACK, bool CSG>
 __global__ void __launch_bounds__(BLOCK) k_intersect(SceneDev S, GenView g, uint32_t n) {
   __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
-  LdsStack<STACK, BLOCK> st;
-  st.init(lds);
+  LdsStack<STACK, BLOCK, CSG> st;
+  extern __shared__ uint32_t csg_lds[];  // CSG_MAX_HITS * 3 * BLOCK words when the scene has CSG operators, else nothing
+  st.init(lds, CSG ? csg_lds : nullptr);
   Counters cnt{};
   ClosestQuery Q;
   Q.init();
-  traverse<ClosestQuery, LdsStack<STACK, BLOCK>, false>(S, load_ray(g, i), Q, st, cnt);
+  traverse<ClosestQuery, LdsStack<STACK, BLOCK, CSG>, false>(S, load_ray(g, i), Q, st, cnt);
   bool hit = Q.best_leaf != 0x7FFFFFFF;
   g.leaf[i] = hit ? Q.best_leaf : -1;
   if (hit) g.t[i] = Q.best_t;
 }
 
 // World::is_shadowed for caller-supplied points.
-template <int STACK>
+template <int STACK, bool CSG>
 __global__ void __launch_bounds__(BLOCK) k_points_shadowed(SceneDev S, uint32_t n, const double* pts, uint8_t* out) {
   __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
-  LdsStack<STACK, BLOCK> st;
-  st.init(lds);
+  LdsStack<STACK, BLOCK, CSG> st;
+  extern __shared__ uint32_t csg_lds[];  // CSG_MAX_HITS * 3 * BLOCK words when the scene has CSG operators, else nothing
+  st.init(lds, CSG ? csg_lds : nullptr);
   Counters cnt{};
   V3 p = v3(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]);
   V3 v = v3(S.light_position[0], S.light_position[1], S.light_position[2]) - p;
@@ -1201,7 +1327,7 @@ __global__ void __launch_bounds__(BLOCK) k_points_shadowed(SceneDev S, uint32_t 
   Q.distance = magnitude(v);
   Q.found = false;
   Ray ray{p, normalize(v)};
-  traverse<ShadowQuery, LdsStack<STACK, BLOCK>, false>(S, ray, Q, st, cnt);
+  traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG>, false>(S, ray, Q, st, cnt);
   out[i] = Q.found ? 1 : 0;
 }
 
@@ -1259,6 +1385,7 @@ struct rt_scene {
   uint64_t scene_bytes = 0;
   double build_seconds = 0;
   int stack_need = 1;
+  bool has_csg = false;
   int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
   GenBuf gens[MAX_GENERATIONS + 1];
   uint32_t* d_counts = nullptr;           // [gen]: length of the next generation
@@ -1393,6 +1520,16 @@ struct SceneBuild {
   std::vector<Gate> gates;
   std::vector<QuadPrim> quad_src, unbounded, band_prims;
   std::vector<ConeBand> bands;
+  // CSG: one root per maximal operator tree
+  std::vector<std::vector<int>> gate_csg;  // roots directly inside each group
+  std::vector<int> top_csg;
+  std::vector<CsgRoot> csg_roots;
+  std::vector<CsgNode> csg_nodes;
+  std::vector<CsgLeaf> csg_leaves;         // ref filled in once the BVH orders are final
+  std::vector<QuadPrim> csg_quads;
+  std::vector<TriIsect> csg_tris;
+  std::vector<uint32_t> csg_unbounded;
+  std::vector<int> csg_root_of;            // operator index -> root index (for roots), else -1
   std::vector<TriIsect> tri_src;
   std::vector<int> tri_xform;  // device xform index or -1 (identity)
   int stack_need = 1;
@@ -1410,6 +1547,96 @@ struct SceneBuild {
     return q;
   }
 
+  TriIsect make_tri(int li) const {
+    const rt_leaf& L = d->leaves[li];
+    const rt_triangle& T = d->triangles[L.tri];
+    TriIsect ti{};
+    for (int a = 0; a < 3; a++) {
+      ti.p1[a] = T.p1[a];
+      ti.e1[a] = T.e1[a];
+      ti.e2[a] = T.e2[a];
+    }
+    ti.leaf = li;
+    ti.xform = is_identity(d->xforms[L.xform].ray_inv) ? -1 : L.xform;
+    return ti;
+  }
+
+  // Records of one CSG root (operator `top` of the description and everything below it) and its item
+  // for the enclosing level; a root without a finite box goes on the list tested for every ray.
+  void csg_items(const std::vector<int>& roots, std::vector<BuildItem>& items) {
+    for (int top : roots) {
+      const rt_csg& C = d->csg[top];
+      CsgRoot R{};
+      R.first_leaf = (uint32_t)csg_leaves.size();
+      R.first_node = (uint32_t)csg_nodes.size();
+      R.gate = C.gate;
+      int last = top;  // operators below `top` follow it directly (parents first)
+      while (last + 1 < d->n_csg) {
+        int a = last + 1;
+        while (a > top) a = d->csg[a].parent;
+        if (a != top) break;
+        last++;
+      }
+      for (int k = top; k <= last; k++) csg_nodes.push_back(CsgNode{d->csg[k].op, k == top ? -1 : d->csg[k].parent - top});
+      R.n_nodes = (uint32_t)(last - top + 1);
+      BuildItem it{};
+      for (int a = 0; a < 3; a++) {
+        it.lo[a] = INFINITY;
+        it.hi[a] = -INFINITY;
+      }
+      bool bounded = true;
+      int possible = 0;
+      for (int li = C.first_leaf; li < C.first_leaf + C.n_leaves; li++) {
+        const rt_leaf& L = d->leaves[li];
+        if (L.type == RT_EMPTY) continue;
+        bool tri = L.type == RT_TRIANGLE || L.type == RT_SMOOTH_TRIANGLE;
+        double lo[3], hi[3];
+        // a cone's parallel-ray root can lie anywhere (src/shape.rs:1097-1102): no box bounds the operator then
+        if (L.type == RT_CONE || !leaf_box(L, d->xforms[L.xform], tri ? &d->triangles[L.tri] : nullptr, lo, hi)) bounded = false;
+        else
+          for (int a = 0; a < 3; a++) {
+            it.lo[a] = fmin(it.lo[a], lo[a]);
+            it.hi[a] = fmax(it.hi[a], hi[a]);
+          }
+        CsgLeaf cl{};
+        if (tri) {
+          cl.ref = make_run(KIND_TRI, (uint32_t)csg_tris.size(), 1);
+          csg_tris.push_back(make_tri(li));
+          possible += 1;
+        } else {
+          cl.ref = make_run(KIND_QUAD, (uint32_t)csg_quads.size(), 1);
+          csg_quads.push_back(make_quad(li));
+          possible += (L.type == RT_SPHERE || L.type == RT_CUBE) ? 2 : (L.type == RT_PLANE ? 1 : 4);
+        }
+        cl.node = L.csg - top;
+        cl.left_mask = L.csg_left;
+        cl.gate = L.gate;
+        csg_leaves.push_back(cl);
+      }
+      R.n_leaves = (uint32_t)csg_leaves.size() - R.first_leaf;
+      if (possible > CSG_MAX_HITS)
+        throw std::length_error("a CSG operator tree whose shapes can yield more than 16 intersections per ray");
+      const uint32_t root_index = (uint32_t)csg_roots.size();
+      csg_roots.push_back(R);
+      if (R.n_leaves == 0) continue;
+      if (!bounded) {
+        csg_unbounded.push_back(root_index);
+        continue;
+      }
+      Gate g{};  // stands for the root in the BVH
+      g.root = REF_NONE;
+      g.parent = C.gate;
+      g.csg = root_index + 1;
+      it.kind = KIND_GATE;
+      it.index = (uint32_t)gates.size();
+      gates.push_back(g);
+      if (bvh.gate_alt.size() < gates.size()) bvh.gate_alt.resize(gates.size(), REF_NONE);
+      bvh.gate_alt[it.index] = make_ref(KIND_GATE, it.index);
+      if (bvh.gate_need.size() < gates.size()) bvh.gate_need.resize(gates.size(), 0);
+      items.push_back(it);
+    }
+  }
+
   // Items of the leaves directly under one group (or the top level).
   void leaf_items(const std::vector<int>& leaves, std::vector<BuildItem>& items) {
     for (int li : leaves) {
@@ -1423,18 +1650,9 @@ struct SceneBuild {
         continue;
       }
       if (tri) {
-        const rt_triangle& T = d->triangles[L.tri];
-        TriIsect ti{};
-        for (int a = 0; a < 3; a++) {
-          ti.p1[a] = T.p1[a];
-          ti.e1[a] = T.e1[a];
-          ti.e2[a] = T.e2[a];
-        }
-        ti.leaf = li;
-        ti.xform = is_identity(X.ray_inv) ? -1 : L.xform;
         it.kind = KIND_TRI;
         it.index = (uint32_t)tri_src.size();
-        tri_src.push_back(ti);
+        tri_src.push_back(make_tri(li));
       } else {
         it.kind = KIND_QUAD;
         it.index = (uint32_t)quad_src.size();
@@ -1478,6 +1696,7 @@ struct SceneBuild {
       if (ok) items.push_back(it);
     }
     leaf_items(gate_leaves[gi], items);
+    csg_items(gate_csg[gi], items);
     const rt_gate& G = d->gates[gi];
     Gate& g = gates[gi];
     copy3x4(g.m, G.to_local);
@@ -1486,7 +1705,7 @@ struct SceneBuild {
       g.bmax[a] = G.bmax[a];
     }
     g.parent = G.parent;
-    g.pad = 0;
+    g.csg = 0;
     double lo[3], hi[3];
     g.root = bvh.build(items, lo, hi);
     if ((size_t)gi >= bvh.gate_need.size()) bvh.gate_need.resize(gi + 1, 0);
@@ -1577,6 +1796,22 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     if (d->gates[i].parent >= i || d->gates[i].parent < -1)
       return fail(RT_ERR_INVALID, "gate parent must precede its children");
   }
+  if (d->n_csg < 0 || (d->n_csg > 0 && !d->csg)) return fail(RT_ERR_INVALID, "bad CSG operator list");
+  for (int i = 0; i < d->n_csg; i++) {
+    const rt_csg& c = d->csg[i];
+    if (c.op < RT_CSG_UNION || c.op > RT_CSG_DIFFERENCE) return fail(RT_ERR_INVALID, "unknown CSG operator");
+    if (c.parent >= i || c.parent < -1) return fail(RT_ERR_INVALID, "CSG parent must precede its children");
+    if (c.gate < -1 || c.gate >= d->n_gates) return fail(RT_ERR_INVALID, "CSG gate out of range");
+    if (c.first_leaf < 0 || c.n_leaves < 0 || (int64_t)c.first_leaf + c.n_leaves > d->n_leaves)
+      return fail(RT_ERR_INVALID, "CSG leaf range out of bounds");
+    if (c.parent >= 0) {
+      const rt_csg& p = d->csg[c.parent];
+      if (c.first_leaf < p.first_leaf || c.first_leaf + c.n_leaves > p.first_leaf + p.n_leaves)
+        return fail(RT_ERR_INVALID, "CSG leaf range not inside its parent's");
+    }
+  }
+  for (int i = 0; i < d->n_gates; i++)
+    if (d->gates[i].csg < -1 || d->gates[i].csg >= d->n_csg) return fail(RT_ERR_INVALID, "gate CSG index out of range");
   for (int i = 0; i < d->n_patterns; i++) {
     const rt_pattern& p = d->patterns[i];
     if (!affine(p.inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) pattern transform");
@@ -1593,6 +1828,9 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     if (L.material < 0 || L.material >= d->n_materials) return fail(RT_ERR_INVALID, "leaf material out of range");
     if (L.xform < 0 || L.xform >= d->n_xforms) return fail(RT_ERR_INVALID, "leaf xform out of range");
     if (L.gate < -1 || L.gate >= d->n_gates) return fail(RT_ERR_INVALID, "leaf gate out of range");
+    if (L.csg < -1 || L.csg >= d->n_csg) return fail(RT_ERR_INVALID, "leaf CSG index out of range");
+    if (L.csg >= 0 && (i < d->csg[L.csg].first_leaf || i >= d->csg[L.csg].first_leaf + d->csg[L.csg].n_leaves))
+      return fail(RT_ERR_INVALID, "leaf outside the leaf range of its CSG operator");
     bool tri = L.type == RT_TRIANGLE || L.type == RT_SMOOTH_TRIANGLE;
     if (tri && (L.tri < 0 || L.tri >= d->n_triangles)) return fail(RT_ERR_INVALID, "leaf triangle out of range");
   }
@@ -1611,14 +1849,35 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   b.d = d;
   b.gate_children.resize(d->n_gates);
   b.gate_leaves.resize(d->n_gates);
+  b.gates.reserve((size_t)d->n_gates + (size_t)d->n_csg);
   b.gates.resize(d->n_gates);
+  b.gate_csg.resize(d->n_gates);
   for (int i = 0; i < d->n_gates; i++) {
-    if (d->gates[i].parent < 0) b.top_gates.push_back(i);
-    else b.gate_children[d->gates[i].parent].push_back(i);
+    const rt_gate& G = d->gates[i];
+    if (G.csg >= 0) {
+      // a group below a CSG operator: only its gate record is needed (eval_csg tests it per leaf)
+      Gate& g = b.gates[i];
+      copy3x4(g.m, G.to_local);
+      for (int a = 0; a < 3; a++) {
+        g.bmin[a] = G.bmin[a];
+        g.bmax[a] = G.bmax[a];
+      }
+      g.root = REF_NONE;
+      g.parent = G.parent;
+      continue;
+    }
+    if (G.parent < 0) b.top_gates.push_back(i);
+    else b.gate_children[G.parent].push_back(i);
   }
   for (int i = 0; i < d->n_leaves; i++) {
+    if (d->leaves[i].csg >= 0) continue;  // reached through its CSG root
     if (d->leaves[i].gate < 0) b.top_leaves.push_back(i);
     else b.gate_leaves[d->leaves[i].gate].push_back(i);
+  }
+  for (int i = 0; i < d->n_csg; i++) {
+    if (d->csg[i].parent >= 0) continue;
+    if (d->csg[i].gate < 0) b.top_csg.push_back(i);
+    else b.gate_csg[d->csg[i].gate].push_back(i);
   }
   std::vector<BuildItem> items;
   for (int gi : b.top_gates) {
@@ -1628,6 +1887,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     if (ok) items.push_back(it);
   }
   b.leaf_items(b.top_leaves, items);
+  b.csg_items(b.top_csg, items);
   double lo[3], hi[3];
   uint32_t root = b.bvh.build(items, lo, hi);
   s->stack_need = b.bvh.stack_need + 2 + 3;  // + root and gate hand-over, + 3 scratch slots of push_if
@@ -1635,7 +1895,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     return fail(RT_ERR_UNSUPPORTED, "scene hierarchy is deeper than the traversal stack");
   if (getenv("RT_AMD_DEBUG")) {
     int occ = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_generation<STACK_SMALL, false, 0>, BLOCK, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_generation<STACK_SMALL, false, 0, false>, BLOCK, 0);
     fprintf(stderr, "[rt_amd] k_generation<%d> blocks of %d per CU (occupancy API): %d\n", STACK_SMALL, BLOCK, occ);
     fprintf(stderr, "[rt_amd] leaves=%d gates=%d nodes=%zu tris=%zu quads=%zu unbounded=%zu bands=%zu stack_need=%d\n", d->n_leaves,
             d->n_gates, b.bvh.nodes.size(), b.bvh.tri_order.size(), b.bvh.quad_order.size(), b.unbounded.size(), b.bands.size(),
@@ -1646,6 +1906,12 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   for (size_t i = 0; i < tris.size(); i++) tris[i] = b.tri_src[b.bvh.tri_order[i]];
   std::vector<QuadPrim> quads(b.bvh.quad_order.size());
   for (size_t i = 0; i < quads.size(); i++) quads[i] = b.quad_src[b.bvh.quad_order[i]];
+  // the shapes below CSG operators follow the BVH-ordered records
+  for (CsgLeaf& cl : b.csg_leaves) cl.ref += (uint32_t)((cl.ref >> 30) == KIND_TRI ? tris.size() : quads.size());
+  tris.insert(tris.end(), b.csg_tris.begin(), b.csg_tris.end());
+  quads.insert(quads.end(), b.csg_quads.begin(), b.csg_quads.end());
+  if (tris.size() > MAX_RUN_FIRST || quads.size() > MAX_RUN_FIRST) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
+  s->has_csg = !b.csg_roots.empty();
   s->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
   // ---- shading tables
@@ -1707,6 +1973,11 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((rc = upload(s, quads, &s->dev.quads))) return rc;
   if ((rc = upload(s, b.gates, &s->dev.gates))) return rc;
   if ((rc = upload(s, b.unbounded, &s->dev.unbounded))) return rc;
+  if ((rc = upload(s, b.csg_roots, &s->dev.csg_roots))) return rc;
+  if ((rc = upload(s, b.csg_nodes, &s->dev.csg_nodes))) return rc;
+  if ((rc = upload(s, b.csg_leaves, &s->dev.csg_leaves))) return rc;
+  if ((rc = upload(s, b.csg_unbounded, &s->dev.csg_unbounded))) return rc;
+  s->dev.n_csg_unbounded = (int32_t)b.csg_unbounded.size();
   if ((rc = upload(s, b.bands, &s->dev.bands))) return rc;
   if ((rc = upload(s, b.band_prims, &s->dev.band_prims))) return rc;
   s->dev.n_bands = (int32_t)b.bands.size();
@@ -1757,6 +2028,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     rc = scene_create_impl(desc, device, s);
   } catch (const std::bad_alloc&) {
     rc = fail(RT_ERR_NOMEM, "out of host memory while building the scene");
+  } catch (const std::length_error& e) {
+    rc = fail(RT_ERR_UNSUPPORTED, e.what());
   } catch (const std::exception& e) {
     rc = fail(RT_ERR_INVALID, e.what());
   }
@@ -1899,26 +2172,32 @@ struct GenLaunch {
   unsigned long long* stats;
 };
 
-template <int STACK, bool COUNT>
+constexpr unsigned CSG_LDS_BYTES = CSG_MAX_HITS * 3 * BLOCK * sizeof(uint32_t);
+
+template <int STACK, bool COUNT, bool CSG>
 void launch_generation_mode(rt_scene* s, int mode, const GenLaunch& a) {
   dim3 grid(blocks_for(a.n)), block(BLOCK);
-  static const unsigned extra_lds = getenv("RT_AMD_EXTRA_LDS") ? (unsigned)atoi(getenv("RT_AMD_EXTRA_LDS")) : 0u;
+  static const unsigned env_lds = getenv("RT_AMD_EXTRA_LDS") ? (unsigned)atoi(getenv("RT_AMD_EXTRA_LDS")) : 0u;
+  const unsigned extra_lds = (CSG ? CSG_LDS_BYTES : 0u) + env_lds;
 #define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_capacity, a.remaining, a.next_count, a.stats, a.cam, a.tiles, a.tiles_x, a.img
   switch (mode) {
-    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
-    case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
-    default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
+    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
+    case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1, CSG>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
+    default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2, CSG>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
   }
 #undef RT_GEN_ARGS
 }
 
 void launch_generation(rt_scene* s, int mode, bool count, const GenLaunch& a) {
-  if (pick_stack(s->stack_need) == STACK_SMALL) {
-    if (count) launch_generation_mode<STACK_SMALL, true>(s, mode, a);
-    else launch_generation_mode<STACK_SMALL, false>(s, mode, a);
+  if (s->has_csg) {  // scenes with CSG operators: the kernels that carry eval_csg (64-entry stack)
+    if (count) launch_generation_mode<64, true, true>(s, mode, a);
+    else launch_generation_mode<64, false, true>(s, mode, a);
+  } else if (pick_stack(s->stack_need) == STACK_SMALL) {
+    if (count) launch_generation_mode<STACK_SMALL, true, false>(s, mode, a);
+    else launch_generation_mode<STACK_SMALL, false, false>(s, mode, a);
   } else {
-    if (count) launch_generation_mode<64, true>(s, mode, a);
-    else launch_generation_mode<64, false>(s, mode, a);
+    if (count) launch_generation_mode<64, true, false>(s, mode, a);
+    else launch_generation_mode<64, false, false>(s, mode, a);
   }
 }
 
@@ -2309,10 +2588,12 @@ extern "C" int rt_intersect_hit(rt_scene* s, uint64_t n, const double* rays6, do
   int rc = load_user_rays(s, n, rays6);
   if (rc) return rc;
   dim3 grid(blocks_for(n)), block(BLOCK);
-  if (pick_stack(s->stack_need) == STACK_SMALL)
-    hipLaunchKernelGGL((k_intersect<STACK_SMALL>), grid, block, 0, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
+  if (s->has_csg)
+    hipLaunchKernelGGL((k_intersect<64, true>), grid, block, CSG_LDS_BYTES, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
+  else if (pick_stack(s->stack_need) == STACK_SMALL)
+    hipLaunchKernelGGL((k_intersect<STACK_SMALL, false>), grid, block, 0, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
   else
-    hipLaunchKernelGGL((k_intersect<64>), grid, block, 0, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
+    hipLaunchKernelGGL((k_intersect<64, false>), grid, block, 0, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
   double* d_t = (double*)s->stage;
   int32_t* d_leaf = (int32_t*)(d_t + n);
   hipLaunchKernelGGL(k_output_rays, grid, block, 0, s->stream, s->gens[0].view, (uint32_t)n, (double*)nullptr, d_leaf,
@@ -2335,10 +2616,12 @@ extern "C" int rt_is_shadowed(rt_scene* s, uint64_t n, const double* points3, ui
   uint8_t* d_out = (uint8_t*)(d_pts + n * 3);
   HIP_TRY(hipMemcpyAsync(d_pts, points3, n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
   dim3 grid(blocks_for(n)), block(BLOCK);
-  if (pick_stack(s->stack_need) == STACK_SMALL)
-    hipLaunchKernelGGL((k_points_shadowed<STACK_SMALL>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
+  if (s->has_csg)
+    hipLaunchKernelGGL((k_points_shadowed<64, true>), grid, block, CSG_LDS_BYTES, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
+  else if (pick_stack(s->stack_need) == STACK_SMALL)
+    hipLaunchKernelGGL((k_points_shadowed<STACK_SMALL, false>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
   else
-    hipLaunchKernelGGL((k_points_shadowed<64>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
+    hipLaunchKernelGGL((k_points_shadowed<64, false>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(shadowed, d_out, n, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));

@@ -82,11 +82,32 @@ struct alignas(32) Gate {
   // the group's ray transform is the identity and its reference box contains everything under it,
   // so for such a ray the reference's gate is an ordinary slab test that the BVH already performs.
   uint32_t skippable;
-  uint32_t pad;
+  uint32_t csg;  // 0: a group; k + 1: stands for CSG root k, nothing else of the record is used
   double m[12];  // rows 0..2 of to_local
   double bmin[3], bmax[3];
 };
 static_assert(sizeof(Gate) == 160, "Gate layout");
+
+// CSG (reference src/shape.rs:1339-1354, src/intersect.rs:278-328).  A root is a maximal operator
+// tree; a ray that reaches it collects the intersections of all leaves below (at most
+// CSG_MAX_HITS), sorts them and runs every operator's filter, innermost first.
+constexpr int CSG_MAX_HITS = 16;
+struct CsgRoot {
+  uint32_t first_leaf, n_leaves;  // into csg_leaves
+  uint32_t first_node, n_nodes;   // into csg_nodes, parents before children
+  int32_t gate;                   // innermost group around the root (its gates are the traversal's business)
+  int32_t pad[3];
+};
+struct CsgNode {
+  int32_t op;      // rt_csg_op
+  int32_t parent;  // index into csg_nodes relative to the root's first_node, or -1
+};
+struct CsgLeaf {
+  uint32_t ref;        // KIND_TRI / KIND_QUAD reference into tris / quads (run of one)
+  int32_t node;        // innermost operator, relative to the root's first_node
+  uint32_t left_mask;  // bit k: counts as a left-operand intersection for the k-th operator above
+  int32_t gate;        // innermost group around the leaf
+};
 
 // Per-leaf shading lookup, indexed by depth-first leaf index.
 struct LeafShade {
@@ -132,6 +153,10 @@ struct SceneDev {
   const QuadPrim* band_prims;
   const uint32_t* band_start;  // direction grid over bands (band_grid.h), null when band_grid_n == 0
   const uint32_t* band_items;
+  const CsgRoot* csg_roots;
+  const CsgNode* csg_nodes;
+  const CsgLeaf* csg_leaves;
+  const uint32_t* csg_unbounded;  // roots without a finite box: evaluated for every ray
   const LeafShade* leaves;
   const XformDev* xforms;
   const TriShade* tri_shade;
@@ -143,6 +168,8 @@ struct SceneDev {
   int32_t n_leaves;
   int32_t n_bands;
   int32_t band_grid_n;
+  int32_t n_csg_unbounded;
+  int32_t pad;
   double light_intensity[3];
   double light_position[3];
 };

@@ -403,6 +403,7 @@ Shape shape_of(const Json& j, const std::string& base_dir) {  // src/scene.rs:95
     if (kids) {
       if (kids->items.size() < 2) throw Panic("CSG union must have at least two operands.");
       s.kind = Shape::Csg;
+      s.type = ty == "union" ? RT_CSG_UNION : (ty == "intersection" ? RT_CSG_INTERSECTION : RT_CSG_DIFFERENCE);
       s.children.push_back(shape_of(kids->items[0], base_dir));
       s.children.push_back(shape_of(kids->items[1], base_dir));
     } else {
@@ -706,15 +707,86 @@ struct Flattener {
     int material = -1, xform = -1;
   };
 
-  void walk(const Shape& s, const Mat4& ray_acc, bool has_parent, const Mat4& parent, int gate, Share* share) {
-    if (s.kind == Shape::Csg)
-      throw std::invalid_argument("CSG shapes (union / intersection / difference) are not supported on the device path");
+  // Left operands of the enclosing CSG operators, innermost last (for Shape::includes).
+  std::vector<const Shape*> left_operands;
+
+  // PartialEq of shapes as `includes` uses it (src/shape.rs:69-102, 203-209, 450-467): kind and
+  // parameters, the local transform and the material, compared with the reference's tolerances.
+  static bool near(double a, double b) { return std::fabs(a - b) < 0.0001; }
+  static bool pattern_eq(const Pattern& a, const Pattern& b) {
+    if (a.type != b.type) return false;
+    for (int i = 0; i < 16; i++)
+      if (!near(a.transform.m[i], b.transform.m[i])) return false;
+    auto col = [](const double* x, const double* y) { return near(x[0], y[0]) && near(x[1], y[1]) && near(x[2], y[2]); };
+    switch (a.type) {
+      case RT_PAT_NULL:
+      case RT_PAT_POINT: return true;
+      case RT_PAT_IDENTITY: return col(a.a, b.a);
+      case RT_PAT_BLEND: return a.first && b.first && a.second && b.second && pattern_eq(*a.first, *b.first) && pattern_eq(*a.second, *b.second);
+      default: return col(a.a, b.a) && col(a.b, b.b);
+    }
+  }
+  static bool leaf_eq(const Shape& a, const Shape& b) {
+    if (a.kind != Shape::Leaf || b.kind != Shape::Leaf || a.type != b.type) return false;
+    auto v3 = [](const double* x, const double* y) { return near(x[0], y[0]) && near(x[1], y[1]) && near(x[2], y[2]); };
+    switch (a.type) {
+      case RT_CONE:
+      case RT_CYLINDER:
+        if (!(a.minimum == b.minimum && a.maximum == b.maximum && a.closed == b.closed)) return false;
+        break;
+      case RT_PLANE:
+        if (!v3(a.plane_normal, b.plane_normal)) return false;
+        break;
+      case RT_TRIANGLE:
+      case RT_SMOOTH_TRIANGLE:
+        if (!(v3(a.tri.p1, b.tri.p1) && v3(a.p2, b.p2) && v3(a.p3, b.p3) && v3(a.tri.e1, b.tri.e1) && v3(a.tri.e2, b.tri.e2) &&
+              v3(a.tri.normal, b.tri.normal)))
+          return false;
+        if (a.type == RT_SMOOTH_TRIANGLE && !(v3(a.tri.n1, b.tri.n1) && v3(a.tri.n2, b.tri.n2) && v3(a.tri.n3, b.tri.n3))) return false;
+        break;
+      default: break;
+    }
+    for (int i = 0; i < 16; i++)
+      if (!near(a.transform.m[i], b.transform.m[i])) return false;
+    const Material &m = a.material, &n = b.material;
+    if (!(near(m.color[0], n.color[0]) && near(m.color[1], n.color[1]) && near(m.color[2], n.color[2]))) return false;
+    if (m.pattern.has_value() != n.pattern.has_value()) return false;
+    if (m.pattern && !pattern_eq(*m.pattern, *n.pattern)) return false;
+    return m.ambient == n.ambient && m.diffuse == n.diffuse && m.specular == n.specular && m.shininess == n.shininess &&
+           m.reflective == n.reflective && m.refractive_index == n.refractive_index && m.transparency == n.transparency;
+  }
+  static bool includes(const Shape& tree, const Shape& leaf) {  // src/shape.rs:450-467
+    if (tree.kind == Shape::Leaf) return leaf_eq(tree, leaf);
+    for (const Shape& c : tree.children)
+      if (includes(c, leaf)) return true;
+    return false;
+  }
+
+  void walk(const Shape& s, const Mat4& ray_acc, bool has_parent, const Mat4& parent, int gate, Share* share, int csg = -1) {
     Mat4 local_inv = s.transform.inverse_or_panic("Shape transform should have an inverse.");
     Mat4 ray_inv = has_parent ? local_inv * ray_acc : local_inv;
+    if (s.kind == Shape::Csg) {
+      // a transform level like a group, without the bounding-box gate (src/shape.rs:1339-1354)
+      if (left_operands.size() >= 32) throw std::invalid_argument("CSG operators nested deeper than 32 levels");
+      rt_csg c{};
+      c.op = s.type;
+      c.parent = csg;
+      c.gate = gate;
+      c.first_leaf = (int32_t)out.leaves.size();
+      out.csg.push_back(c);
+      int ci = (int)out.csg.size() - 1;
+      Mat4 child_parent = has_parent ? parent * s.transform : s.transform;
+      left_operands.push_back(&s.children[0]);
+      for (const Shape& ch : s.children) walk(ch, ray_inv, true, child_parent, gate, nullptr, ci);
+      left_operands.pop_back();
+      out.csg[ci].n_leaves = (int32_t)out.leaves.size() - out.csg[ci].first_leaf;
+      return;
+    }
     if (s.kind == Shape::Group) {
       if (s.children.empty()) return;  // src/shape.rs:1186-1188
       rt_gate g{};
       g.parent = gate;
+      g.csg = csg;
       memcpy(g.to_local, ray_inv.m, sizeof(g.to_local));
       Box b = reference_bounds(s);
       memcpy(g.bmin, b.lo, sizeof(g.bmin));
@@ -723,7 +795,7 @@ struct Flattener {
       int gi = (int)out.gates.size() - 1;
       Mat4 child_parent = has_parent ? parent * s.transform : s.transform;
       Share group_share;
-      for (const Shape& c : s.children) walk(c, ray_inv, true, child_parent, gi, &group_share);
+      for (const Shape& c : s.children) walk(c, ray_inv, true, child_parent, gi, &group_share, csg);
       return;
     }
     rt_leaf L{};
@@ -734,6 +806,10 @@ struct Flattener {
     L.maximum = s.maximum;
     memcpy(L.plane_normal, s.plane_normal, sizeof(L.plane_normal));
     L.tri = -1;
+    L.csg = csg;
+    L.csg_left = 0;
+    for (size_t k = 0; k < left_operands.size(); k++)  // bit 0 = innermost operator
+      if (includes(*left_operands[left_operands.size() - 1 - k], s)) L.csg_left |= 1u << k;
     bool is_tri = s.type == RT_TRIANGLE || s.type == RT_SMOOTH_TRIANGLE;
     bool plain_tri = is_tri && is_default_material(s.material) && is_identity(s.transform);
     if (plain_tri && share && share->material >= 0) {
@@ -786,6 +862,8 @@ rt_scene_desc FlatWorld::desc() const {
   d.n_triangles = (int32_t)triangles.size();
   d.n_materials = (int32_t)materials.size();
   d.n_patterns = (int32_t)patterns.size();
+  d.n_csg = (int32_t)csg.size();
+  d.csg = csg.data();
   d.leaves = leaves.data();
   d.gates = gates.data();
   d.xforms = xforms.data();

@@ -49,7 +49,7 @@ struct Material {  // src/light.rs:96-112 defaults
 
 struct Shape {
   enum Kind { Leaf, Group, Csg } kind = Leaf;
-  int type = RT_EMPTY;  // rt_leaf_type for leaves
+  int type = RT_EMPTY;  // rt_leaf_type for leaves, rt_csg_op for CSG operators
   int closed = 0;
   double minimum = 0, maximum = 0;
   double plane_normal[3] = {0, 1, 0};
@@ -92,6 +92,7 @@ std::map<std::string, Shape> obj_groups_from_text(const std::string& text, size_
 struct FlatWorld {
   std::vector<rt_leaf> leaves;
   std::vector<rt_gate> gates;
+  std::vector<rt_csg> csg;
   std::vector<rt_xform> xforms;
   std::vector<rt_triangle> triangles;
   std::vector<rt_material> materials;

@@ -201,3 +201,64 @@ def test_download_copies_frames_to_pinned_memory(pkg, root):
         gpu.wait()
         assert torch.equal(dst[offset:offset + n], src[offset:offset + n].cpu())
         assert int(dst[offset + n:].sum()) == 0 and int(dst[:offset].sum()) == 0
+
+
+def _csg_world(pkg, root, shapes):
+    base = json.load(open(os.path.join(root, "scenes", "example.json")))
+    return pkg.Scene(json.dumps(dict(base, shapes=shapes)), root, device=0)
+
+
+def test_csg_known_answers(pkg, root):
+    """The reference's own CSG tests (src/shape.rs:2173-2223): a ray misses a union of a sphere and a
+    cube; a ray hits a union of two spheres at t = 4 (first sphere) -- and the filters of the three
+    operators on two overlapping spheres."""
+    miss = _csg_world(pkg, root, [{"ty": "union", "children": [{"ty": "sphere"}, {"ty": "cube"}]}])
+    t, leaf = miss.intersect_hit(np.array([[0, 2, -5, 0, 0, 1]], np.float64))
+    assert leaf[0] == -1 and np.isnan(t[0])
+    z05 = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0.5, 0, 0, 0, 1]
+    ray = np.array([[0, 0, -5, 0, 0, 1]], np.float64)
+    # spheres at z = 0 and z = 0.5: surfaces at t = 4, 4.5, 6, 6.5
+    for op, want_t, want_leaf in [("union", 4.0, 0), ("intersection", 4.5, 1), ("difference", 4.0, 0)]:
+        s = _csg_world(pkg, root, [{"ty": op, "children": [{"ty": "sphere"}, {"ty": "sphere", "transform": z05}]}])
+        t, leaf = s.intersect_hit(ray)
+        assert t[0] == want_t and leaf[0] == want_leaf
+    # from inside the union (origin at z = 0.25 is inside both): only the far outer surface remains
+    s = _csg_world(pkg, root, [{"ty": "union", "children": [{"ty": "sphere"}, {"ty": "sphere", "transform": z05}]}])
+    t, leaf = s.intersect_hit(np.array([[0, 0, 0.25, 0, 0, 1]], np.float64))
+    assert t[0] == 1.25 and leaf[0] == 1
+    # difference seen from behind: the first surface is the second sphere's cut into the first (t = 5 - 0.5 ... )
+    s = _csg_world(pkg, root, [{"ty": "difference", "children": [{"ty": "sphere"}, {"ty": "sphere", "transform": z05}]}])
+    t, leaf = s.intersect_hit(np.array([[0, 0, 5, 0, 0, -1]], np.float64))
+    assert t[0] == 5.5 and leaf[0] == 1  # z = -0.5: the second sphere's near side, inside the first
+
+
+def test_csg_operators_match_the_oracle_ray_by_ray(pkg, root):
+    base = json.load(open(os.path.join(root, "scenes", "example.json")))
+    z05 = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0.5, 0, 0, 0, 1]
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-3, 3, (400, 3))
+    d = rng.uniform(-0.6, 0.6, (400, 3)) - o
+    rays = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1)
+    rays[:3] = [[0, 0, -5, 0, 0, 1], [0, 0, 0.25, 0, 0, 1], [0, 0, 5, 0, 0, -1]]
+    for op in ("union", "intersection", "difference"):
+        for right in ({"ty": "sphere", "transform": z05}, {"ty": "cube", "transform": z05},
+                      {"ty": op, "children": [{"ty": "capped_cylinder", "transform": z05}, {"ty": "sphere"}]}):
+            shapes = [{"ty": op, "children": [{"ty": "sphere"}, right]}]
+            text = json.dumps(dict(base, shapes=shapes))
+            gpu, cpu = pkg.Scene(text, root, device=0), orc.OracleScene(text, root)
+            t, leaf = gpu.intersect_hit(rays)
+            wt, wleaf = cpu.intersect_hit(rays)
+            assert np.array_equal(leaf, wleaf)
+            assert np.array_equal(np.isnan(t), np.isnan(wt)) and np.allclose(t[leaf >= 0], wt[leaf >= 0], rtol=1e-12)
+            rgb, _, st = gpu.color_at(rays)
+            want, _, counts = cpu.color_at(rays)
+            assert np.abs(rgb - want).max() <= 1e-9 and [st.primary, st.shadow, st.reflect, st.refract] == counts
+
+
+def test_csg_with_too_many_possible_hits_is_refused(pkg, root):
+    cyl = {"ty": "capped_cylinder"}
+    tree = {"ty": "union", "children": [{"ty": "union", "children": [cyl, cyl]},
+                                        {"ty": "union", "children": [{"ty": "union", "children": [cyl, cyl]}, {"ty": "sphere"}]}]}
+    with pytest.raises(pkg.RtError) as e:
+        _csg_world(pkg, root, [tree])  # 4 x 4 + 2 = 18 possible intersections per ray
+    assert e.value.status == -2

@@ -79,9 +79,18 @@ def test_loader_errors_keep_the_reference_messages(pkg):
         load(shapes=[{"ty": "model", "path": "models/absent.obj"}])
     with pytest.raises(pkg.RtError, match="missing field"):
         pkg.Scene('{"canvas_width": 10}', ROOT, device=None)
-    with pytest.raises(pkg.RtError) as e:
-        load(shapes=[{"ty": "union", "children": [{"ty": "sphere"}, {"ty": "cube"}]}])
-    assert e.value.status == -2  # CSG is valid for the reference, unsupported on the device path
+    with pytest.raises(pkg.RtError, match="CSG union must have at least two operands"):
+        load(shapes=[{"ty": "difference", "children": [{"ty": "sphere"}]}])
+
+
+def test_csg_operators_flatten(pkg):
+    """CSG operators are transform levels without a gate; their leaves stay in depth-first order
+    and agree with the oracle's tree."""
+    path = os.path.join(ROOT, "tests", "golden", "csg.json")
+    s = pkg.Scene.from_file(path, base_dir=ROOT, device=None)
+    ref = orc.OracleScene.from_file(path, base_dir=ROOT)
+    assert s.info()["leaves"] == ref.info()["leaves"] == 16
+    assert s.info()["gates"] == 2  # the bowl group and the group below its difference operator
 
 
 def test_empty_groups_and_empty_shapes_flatten(pkg):

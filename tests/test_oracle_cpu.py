@@ -46,9 +46,10 @@ def test_synthetic_generators_match_golden(name, tmp_path):
     assert r["counts"] == [int(c) for c in g["counts"]]
 
 
-def test_allprims_matches_golden():
-    g = np.load(os.path.join(GOLDEN, "allprims.npz"))
-    with open(os.path.join(GOLDEN, "allprims.json")) as f:
+@pytest.mark.parametrize("name", ["allprims", "csg"])
+def test_allprims_matches_golden(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
         s = orc.OracleScene(f.read(), ROOT)
     r = s.render(jobs=4)
     assert np.array_equal(r["hit_leaf"], g["hit_leaf"])
