@@ -926,9 +926,12 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
   if (jobs == 0) throw Panic("assertion failed: size > 0");  // src/parallel.rs:94
   int have = rt_device_count();
   if (have < 0) throw std::runtime_error(rt_last_error());
-  if ((size_t)have < jobs) throw std::runtime_error("-j asks for " + std::to_string(jobs) + " GPUs, " + std::to_string(have) + " visible");
+  if (have == 0) throw std::runtime_error("no GPU visible");
   printf("Rendering using %zu threads...\n", jobs);  // the three lines of src/parallel.rs:188,202-203
   fflush(stdout);
+  // `jobs` counts worker threads in the reference; here one worker drives one GPU, so a request for
+  // more workers than GPUs uses every GPU there is
+  if ((size_t)have < jobs) jobs = (size_t)have;
   FlatWorld flat = flatten(world);
   rt_scene_desc desc = flat.desc();
   rt_camera cam = camera.describe();

@@ -262,3 +262,31 @@ def test_csg_with_too_many_possible_hits_is_refused(pkg, root):
     with pytest.raises(pkg.RtError) as e:
         _csg_world(pkg, root, [tree])  # 4 x 4 + 2 = 18 possible intersections per ray
     assert e.value.status == -2
+
+
+def test_parallel_render_writes_the_reference_ppm(pkg, root, tmp_path):
+    """The drop-in boundary itself: parallel_render(world, camera, jobs, out) (src/parallel.rs:183-204)
+    and the command line of src/main.rs, against Canvas::save of the oracle's render."""
+    import subprocess
+
+    gpu, cpu = load_pair(pkg, root, "pattern", (70, 40))
+    want = orc.ppm_encode(cpu.render(jobs=4)["rgb64"])
+    out = tmp_path / "a.ppm"
+    gpu.parallel_render(4, out)  # more workers than GPUs: every GPU there is
+    assert out.read_bytes() == want
+    # the shipped scene at its own size through the CLI
+    cli = os.path.join(root, "ray-tracer_amd", "lib", "ray-tracer-amd")
+    scene = os.path.join(root, "tests", "golden", "allprims.json")
+    out2 = tmp_path / "b.ppm"
+    p = subprocess.run([cli, "-s", scene, "-o", str(out2), "-j", "1"], capture_output=True, text=True, timeout=120, cwd=root)
+    assert p.returncode == 0, p.stderr
+    assert "Rendering using 1 threads..." in p.stdout and "Saved render to" in p.stdout
+    g = np.load(os.path.join(root, "tests", "golden", "allprims.npz"))
+    got = out2.read_bytes()
+    ref = orc.ppm_encode(g["rgb64"])
+    if got != ref:  # the parity bar allows single pixels off by one level
+        a = np.array(got.split()[4:], dtype=int)
+        b = np.array(ref.split()[4:], dtype=int)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1 and (a != b).sum() <= 5
+    bad = subprocess.run([cli, "-s", os.path.join(root, "absent.json"), "-o", str(out2)], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0
