@@ -886,36 +886,51 @@ FlatWorld flatten(const World& w) {
 // Canvas::save (src/canvas.rs:47-94)
 // ===========================================================================
 std::string ppm_encode(size_t width, size_t height, const uint8_t* rgb8) {
+  // decimal text of every byte value, once: formatting dominates the writer otherwise
+  struct Digits {
+    char text[256][4];
+    uint8_t len[256];
+    Digits() {
+      for (int v = 0; v < 256; v++) len[v] = (uint8_t)snprintf(text[v], sizeof(text[v]), "%d", v);
+    }
+  };
+  static const Digits D;
+  std::string head = "P3\n" + std::to_string(width) + " " + std::to_string(height) + "\n255\n";
   std::string out;
-  out.reserve(width * height * 12 + 32);
-  out += "P3\n" + std::to_string(width) + " " + std::to_string(height) + "\n255\n";
-  char num[3][4];
-  size_t len[3];
+  out.resize(head.size() + width * height * 12 + 2);  // at most "255 255 255" plus a separator per pixel
+  memcpy(&out[0], head.data(), head.size());
+  char* w = &out[head.size()];
+  auto put = [&](unsigned v) {
+    memcpy(w, D.text[v], 4);  // copies the terminator too; the next write overwrites it
+    w += D.len[v];
+  };
   size_t col = 1;
   for (size_t p = 0; p < width * height; p++) {
-    for (int k = 0; k < 3; k++) len[k] = (size_t)snprintf(num[k], sizeof(num[k]), "%u", (unsigned)rgb8[p * 3 + k]);
-    if (col + len[0] > 70) {
-      out += '\n';
-      out.append(num[0], len[0]); out += ' '; out.append(num[1], len[1]); out += ' '; out.append(num[2], len[2]);
-      col = len[0] + len[1] + len[2] + 3;
-    } else if (col + len[0] + len[1] > 70) {
-      out += ' ';
-      out.append(num[0], len[0]); out += '\n'; out.append(num[1], len[1]); out += ' '; out.append(num[2], len[2]);
-      col = len[1] + len[2] + 2;
-    } else if (col + len[0] + len[1] + len[2] > 70) {
-      out += ' ';
-      out.append(num[0], len[0]); out += ' '; out.append(num[1], len[1]); out += '\n'; out.append(num[2], len[2]);
-      col = len[2] + 1;
+    const unsigned a = rgb8[p * 3], b = rgb8[p * 3 + 1], c = rgb8[p * 3 + 2];
+    const size_t la = D.len[a], lb = D.len[b], lc = D.len[c];
+    if (col + la > 70) {
+      *w++ = '\n';
+      put(a); *w++ = ' '; put(b); *w++ = ' '; put(c);
+      col = la + lb + lc + 3;
+    } else if (col + la + lb > 70) {
+      *w++ = ' ';
+      put(a); *w++ = '\n'; put(b); *w++ = ' '; put(c);
+      col = lb + lc + 2;
+    } else if (col + la + lb + lc > 70) {
+      *w++ = ' ';
+      put(a); *w++ = ' '; put(b); *w++ = '\n'; put(c);
+      col = lc + 1;
     } else {
       if (col != 1) {
-        out += ' ';
+        *w++ = ' ';
         col += 1;
       }
-      out.append(num[0], len[0]); out += ' '; out.append(num[1], len[1]); out += ' '; out.append(num[2], len[2]);
-      col += len[0] + len[1] + len[2] + 2;
+      put(a); *w++ = ' '; put(b); *w++ = ' '; put(c);
+      col += la + lb + lc + 2;
     }
   }
-  out += '\n';
+  *w++ = '\n';
+  out.resize((size_t)(w - out.data()));
   return out;
 }
 
