@@ -103,7 +103,14 @@ def main():
     host_frames = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)] if rank == 0 else None
     copy_stream = torch.cuda.ExternalStream(scene.copy_stream_ptr(), device=device)  # the library's copy stream
     buffer_free = [torch.cuda.Event() for _ in range(2)]
-    render_stream = torch.cuda.ExternalStream(scene.stream_ptr(), device=device)  # the library's own stream
+    stream_objects = {}
+
+    def render_stream():  # the library stream the last frame went to
+        p = scene.stream_ptr()
+        if p not in stream_objects:
+            stream_objects[p] = torch.cuda.ExternalStream(p, device=device)
+        return stream_objects[p]
+
     step_no = [0]
 
     def step():
@@ -120,7 +127,7 @@ def main():
             return
         else:
             scene.render_device(rgb8_ptr=gather.mine[k].data_ptr(), part=rank, n_parts=world, wait=False, compact=True)
-            torch.cuda.current_stream().wait_stream(render_stream)
+            torch.cuda.current_stream().wait_stream(render_stream())
             frame = gather(k)  # rank 0: the whole frame
         if rank == 0:
             scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel(),
@@ -188,6 +195,8 @@ def main():
         "flops_per_launch": fl, "bytes_per_launch": by, "frac_fp64_valu": frac_valu, "frac_hbm": frac_hbm,
         "onchip_bytes_per_launch": onchip / launches, "onchip_GBps": onchip / launches / avg_s / 1e9,
         "events_per_frame": events,
+        "overlap": "consecutive frames run on two streams, so a launch shares the GPU with the tail or head of its "
+                   "neighbour: avg_launch_ms is longer than a lone launch (about 0.17 ms) while frames complete faster",
         "note": "no dense contraction on this path, so no MFMA: the ceilings are vector FP64 (78.6 TFLOP/s datasheet, "
                 "which counts an FMA as two; the path is compiled without contraction to match the reference bit for "
                 "bit, so half of that is reachable) and HBM (8 TB/s). bytes_per_launch is the unavoidable HBM traffic "

@@ -225,9 +225,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, u
  * process (src/main.rs:71); this pair has no counterpart there. */
 int rt_scene_wait(rt_scene* scene, rt_stats* total);
 
-/* The HIP stream (hipStream_t) all work of the scene is enqueued on, so that a caller can order
- * its own streams after an asynchronous frame (hipStreamWaitEvent) or make a frame wait for a
- * buffer to be free. */
+/* The HIP stream (hipStream_t) the most recent frame was enqueued on, so that a caller can order
+ * its own streams after it (hipStreamWaitEvent).  Asynchronous frames alternate between two
+ * streams, so ask again after every rt_render. */
 int rt_scene_stream(rt_scene* scene, void** hip_stream);
 
 /* Copies `bytes` from device memory to pinned (page-locked) host memory on the scene's copy

@@ -1378,7 +1378,9 @@ void carve(GenBuf& b) {
 struct rt_scene {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;  // rt_download
+  hipStream_t frame_stream = nullptr;  // asynchronous frames alternate between stream and frame_stream
+  hipStream_t last_stream = nullptr;   // where the most recent frame was enqueued
+  hipStream_t copy_stream = nullptr;   // rt_download
   hipEvent_t copy_order = nullptr;
   SceneDev dev{};
   std::vector<void*> allocs;
@@ -1778,6 +1780,10 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     (void)hipStreamDestroy(s->copy_stream);
   }
   if (s->copy_order) (void)hipEventDestroy(s->copy_order);
+  if (s->frame_stream) {
+    (void)hipStreamSynchronize(s->frame_stream);
+    (void)hipStreamDestroy(s->frame_stream);
+  }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -1840,6 +1846,8 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   HIP_TRY(hipSetDevice(device));
   s->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&s->frame_stream, hipStreamNonBlocking));
+  s->last_stream = s->stream;
   HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&s->copy_order, hipEventDisableTiming));
 
@@ -2170,6 +2178,7 @@ struct GenLaunch {
   uint32_t tiles_x;
   ImageOut img;
   unsigned long long* stats;
+  hipStream_t stream;
 };
 
 constexpr unsigned CSG_LDS_BYTES = CSG_MAX_HITS * 3 * BLOCK * sizeof(uint32_t);
@@ -2181,9 +2190,9 @@ void launch_generation_mode(rt_scene* s, int mode, const GenLaunch& a) {
   const unsigned extra_lds = (CSG ? CSG_LDS_BYTES : 0u) + env_lds;
 #define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_capacity, a.remaining, a.next_count, a.stats, a.cam, a.tiles, a.tiles_x, a.img
   switch (mode) {
-    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
-    case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1, CSG>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
-    default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2, CSG>), grid, block, extra_lds, s->stream, RT_GEN_ARGS); break;
+    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
+    case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1, CSG>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
+    default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2, CSG>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
   }
 #undef RT_GEN_ARGS
 }
@@ -2287,8 +2296,12 @@ int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
   rt_scene::FrameSlot& f = s->slots[s->next_slot];
   int rc = collect_frame(s, f);  // the slot's previous frame, FRAME_SLOTS frames ago
   if (rc) return rc;
+  // consecutive frames go to alternating streams: they do not depend on each other, and the tail of
+  // one kernel (few waves left) overlaps the head of the next
+  hipStream_t stream = (s->next_slot & 1) ? s->frame_stream : s->stream;
+  s->last_stream = stream;
   s->next_slot = (s->next_slot + 1) % rt_scene::FRAME_SLOTS;
-  HIP_TRY(hipMemsetAsync(f.d_stats, 0, STAT_WORDS * sizeof(unsigned long long), s->stream));
+  HIP_TRY(hipMemsetAsync(f.d_stats, 0, STAT_WORDS * sizeof(unsigned long long), stream));
   GenLaunch a;
   a.cur = s->gens[0].view;
   a.next = s->gens[1].view;
@@ -2301,13 +2314,14 @@ int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
   a.tiles_x = in.tiles_x;
   a.img = in.img;
   a.stats = f.d_stats;
-  HIP_TRY(hipEventRecord(f.begin, s->stream));
+  a.stream = stream;
+  HIP_TRY(hipEventRecord(f.begin, stream));
   launch_generation(s, 0, (in.flags & RT_FLAG_COUNTERS) != 0, a);
-  HIP_TRY(hipEventRecord(f.end, s->stream));
+  HIP_TRY(hipEventRecord(f.end, stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(f.h_stats, f.d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                         s->stream));
-  HIP_TRY(hipEventRecord(f.done, s->stream));
+                         stream));
+  HIP_TRY(hipEventRecord(f.done, stream));
   f.primary = primary;
   f.pending = true;
   return RT_OK;
@@ -2346,6 +2360,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     a.tiles_x = in.tiles_x;
     a.img = in.img;
     a.stats = s->d_stats;
+    a.stream = s->stream;
     int mode = (g == 0 && in.camera) ? (direct ? 0 : 1) : 2;
     HIP_TRY(hipEventRecord(s->ev[g * 2 + 0], s->stream));
     launch_generation(s, mode, count, a);
@@ -2450,6 +2465,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   if ((flags & RT_FLAG_ASYNC) && s->max_children == 0) return enqueue_direct_frame(s, in, valid);
   int rc = collect_all(s);  // frames still in flight finish first
   if (rc) return rc;
+  s->last_stream = s->stream;
   rc = run_pipeline(s, in, stats);
   if (rc) return rc;
   if (stats) {
@@ -2472,7 +2488,7 @@ extern "C" int rt_scene_wait(rt_scene* s, rt_stats* total) {
 
 extern "C" int rt_scene_stream(rt_scene* s, void** hip_stream) {
   if (!s || !hip_stream) return fail(RT_ERR_INVALID, "null argument");
-  *hip_stream = (void*)s->stream;
+  *hip_stream = (void*)s->last_stream;
   return RT_OK;
 }
 
@@ -2486,7 +2502,7 @@ extern "C" int rt_download(rt_scene* s, const void* src_dev, void* dst_host, uin
   if (!s || (bytes && (!src_dev || !dst_host))) return fail(RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(s->device));
   if (bytes == 0) return RT_OK;
-  hipStream_t after = after_stream ? (hipStream_t)after_stream : s->stream;
+  hipStream_t after = after_stream ? (hipStream_t)after_stream : s->last_stream;
   HIP_TRY(hipEventRecord(s->copy_order, after));
   HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order, 0));
   // a plain asynchronous copy: the runtime moves it with a DMA engine, which leaves the compute units
