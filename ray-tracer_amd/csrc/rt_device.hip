@@ -364,9 +364,10 @@ struct ContainerQuery {
 // Per-lane stack in LDS: entry e of thread t lives at stack[e * BLOCK + t], so
 // the 64 lanes of a wave hit 64 consecutive banks.
 #ifndef RT_PRIVATE_STACK
-template <int STACK, int BLOCK, bool CSG = false>
+template <int STACK, int BLOCK, bool CSG = false, bool UNIFORM = false>
 struct LdsStack {
   static constexpr bool WITH_CSG = CSG;  // the kernels built for scenes with CSG operators carry eval_csg
+  static constexpr bool UNIFORM_NODES = UNIFORM;  // ... and those for large hierarchies the scalar node path
   static constexpr int THREADS = BLOCK;
   uint32_t* base;
   uint32_t* csg;  // this lane's column of the CSG hit list (dynamic LDS), or null when the scene has no CSG
@@ -394,9 +395,10 @@ struct LdsStack {
 #define RT_STACK_LDS(n) (n)
 #else
 // Experiment: per-lane stack in private (scratch) memory instead of LDS.
-template <int STACK, int BLOCK, bool CSG = false>
+template <int STACK, int BLOCK, bool CSG = false, bool UNIFORM = false>
 struct LdsStack {
   static constexpr bool WITH_CSG = CSG;
+  static constexpr bool UNIFORM_NODES = UNIFORM;
   static constexpr int THREADS = BLOCK;
   uint32_t slot[STACK];
   uint32_t* csg;
@@ -465,6 +467,33 @@ struct F4 {
 DEV F4 load_f4(const char* base, uint32_t off) {
   float4 q = *reinterpret_cast<const float4*>(base + off);
   return F4{{q.x, q.y, q.z, q.w}};
+}
+
+// The same 16 bytes for a wave-uniform address: read through the constant address space, so the
+// load goes through the scalar cache into SGPRs and not through the per-CU vector data path, whose
+// return bandwidth (64 B per clock, 1 KB per wave instruction whatever the addresses) bounds the
+// node loop.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+DEV F4 load_f4_uniform(const char* base, uint32_t off) {
+  f32x4 q = *(const __attribute__((address_space(4))) f32x4*)(base + off);
+  return F4{{q.x, q.y, q.z, q.w}};
+}
+
+// Slab tests of the four children of one node: entry distance (INFINITY when missed) per child,
+// and the references of missed children cleared.
+DEV void slab4(const RayBox& rb, float qhi, const F4& nx, const F4& ny, const F4& nz, const F4& fx, const F4& fy,
+               const F4& fz, float tn[4], uint32_t c[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    float tnear = fmaxf(fmaxf(fmaf(nx.v[k], rb.inv_n[0], -rb.c_n[0]), fmaf(ny.v[k], rb.inv_n[1], -rb.c_n[1])),
+                        fmaf(nz.v[k], rb.inv_n[2], -rb.c_n[2]));
+    float tfar = fminf(fminf(fmaf(fx.v[k], rb.inv_f[0], -rb.c_f[0]), fmaf(fy.v[k], rb.inv_f[1], -rb.c_f[1])),
+                       fmaf(fz.v[k], rb.inv_f[2], -rb.c_f[2]));
+    bool hit = fmaxf(tnear, 0.0f) <= fminf(tfar, qhi);
+    tn[k] = hit ? tnear : INFINITY;
+    if (!hit) c[k] = REF_NONE;
+  }
 }
 
 template <class Query>
@@ -644,27 +673,44 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
   // gates are already replaced by their subtrees
   const uint32_t child_off = rb.tiny ? 96u : 112u;
   uint32_t cur = rb.tiny ? S.root : S.root_alt;
+  // do all lanes that traverse pick the same near planes and the same child list?
+  uint32_t un[3] = {0, 0, 0}, uchild = 0;
+  bool same_signs = false;
+  if constexpr (Stack::UNIFORM_NODES) {
+    for (int a = 0; a < 3; a++) un[a] = (uint32_t)__builtin_amdgcn_readfirstlane(rb.off_near[a]);
+    uchild = __builtin_amdgcn_readfirstlane(child_off);
+    same_signs = __builtin_amdgcn_ballot_w64(rb.off_near[0] != un[0] || rb.off_near[1] != un[1] ||
+                                             rb.off_near[2] != un[2] || child_off != uchild) == 0;
+  }
   RT_TSTAMP(cnt, 0);
   while (cur != REF_NONE) {
     while ((cur >> 30) == KIND_INNER) {
       const uint32_t nd = cur << 7;  // byte offset of the node (inner kind bits are zero)
       if (COUNT) cnt.node_visits++;
-      F4 nx = load_f4(nodes, nd + rb.off_near[0]), ny = load_f4(nodes, nd + rb.off_near[1]),
-         nz = load_f4(nodes, nd + rb.off_near[2]);
-      F4 fx = load_f4(nodes, nd + (rb.off_near[0] ^ 16u)), fy = load_f4(nodes, nd + (rb.off_near[1] ^ 16u)),
-         fz = load_f4(nodes, nd + (rb.off_near[2] ^ 16u));
-      uint4 ch = *reinterpret_cast<const uint4*>(nodes + nd + child_off);
-      uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
       float tn[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        float tnear = fmaxf(fmaxf(fmaf(nx.v[k], rb.inv_n[0], -rb.c_n[0]), fmaf(ny.v[k], rb.inv_n[1], -rb.c_n[1])),
-                            fmaf(nz.v[k], rb.inv_n[2], -rb.c_n[2]));
-        float tfar = fminf(fminf(fmaf(fx.v[k], rb.inv_f[0], -rb.c_f[0]), fmaf(fy.v[k], rb.inv_f[1], -rb.c_f[1])),
-                           fmaf(fz.v[k], rb.inv_f[2], -rb.c_f[2]));
-        bool hit = fmaxf(tnear, 0.0f) <= fminf(tfar, qhi);
-        tn[k] = hit ? tnear : INFINITY;
-        if (!hit) c[k] = REF_NONE;
+      uint32_t c[4];
+      bool together = false;
+      uint32_t ucur = 0;
+      if constexpr (Stack::UNIFORM_NODES) {
+        ucur = __builtin_amdgcn_readfirstlane(cur);
+        together = same_signs && __builtin_amdgcn_ballot_w64(cur != ucur) == 0;
+      }
+      if (together) {
+        // every lane still in the loop is at this node and picks the same near / far planes
+        const char* np = nodes + ((size_t)ucur << 7);
+        F4 nx = load_f4_uniform(np, un[0]), ny = load_f4_uniform(np, un[1]), nz = load_f4_uniform(np, un[2]);
+        F4 fx = load_f4_uniform(np, un[0] ^ 16u), fy = load_f4_uniform(np, un[1] ^ 16u), fz = load_f4_uniform(np, un[2] ^ 16u);
+        u32x4 ch = *(const __attribute__((address_space(4))) u32x4*)(np + uchild);
+        c[0] = ch.x; c[1] = ch.y; c[2] = ch.z; c[3] = ch.w;
+        slab4(rb, qhi, nx, ny, nz, fx, fy, fz, tn, c);
+      } else {
+        F4 nx = load_f4(nodes, nd + rb.off_near[0]), ny = load_f4(nodes, nd + rb.off_near[1]),
+           nz = load_f4(nodes, nd + rb.off_near[2]);
+        F4 fx = load_f4(nodes, nd + (rb.off_near[0] ^ 16u)), fy = load_f4(nodes, nd + (rb.off_near[1] ^ 16u)),
+           fz = load_f4(nodes, nd + (rb.off_near[2] ^ 16u));
+        uint4 ch = *reinterpret_cast<const uint4*>(nodes + nd + child_off);
+        c[0] = ch.x; c[1] = ch.y; c[2] = ch.z; c[3] = ch.w;
+        slab4(rb, qhi, nx, ny, nz, fx, fy, fz, tn, c);
       }
       // nearest hit child stays in a register, the other hit children go on the stack
       bool lt = tn[1] < tn[0];
@@ -1023,13 +1069,13 @@ DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y
 #ifndef RT_MIN_WAVES_SPAWN
 #define RT_MIN_WAVES_SPAWN 3
 #endif
-template <int STACK, bool COUNT, int MODE, bool CSG>
+template <int STACK, bool COUNT, int MODE, bool CSG, bool UNIFORM>
 __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES_SPAWN)
     k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_capacity, int remaining,
                  uint32_t* next_count, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
                  uint32_t tiles_x, ImageOut img) {
   __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
-  LdsStack<STACK, BLOCK, CSG> st;
+  LdsStack<STACK, BLOCK, CSG, UNIFORM> st;
   extern __shared__ uint32_t csg_lds[];  // CSG_MAX_HITS * 3 * BLOCK words when the scene has CSG operators, else nothing
   st.init(lds, CSG ? csg_lds : nullptr);
 #ifdef RT_STAMPS
@@ -1054,7 +1100,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
   ClosestQuery Q;
   Q.init();
   RT_STAMP(0);  // ray generation
-  if (active) traverse<ClosestQuery, LdsStack<STACK, BLOCK, CSG>, COUNT>(S, ray, Q, st, ct);
+  if (active) traverse<ClosestQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM>, COUNT>(S, ray, Q, st, ct);
   RT_STAMP(1);  // closest-hit traversal
   const bool hit = active && Q.best_leaf != 0x7FFFFFFF;
   const int leaf = hit ? Q.best_leaf : -1;
@@ -1123,7 +1169,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
       if (m.flags & 8) {  // n1 / n2 are consumed: refraction or Schlick (src/intersect.rs:191-234)
         ContainerQuery C;
         C.init(leaf);
-        traverse<ContainerQuery, LdsStack<STACK, BLOCK, CSG>, COUNT>(S, ray, C, st, ct);
+        traverse<ContainerQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM>, COUNT>(S, ray, C, st, ct);
         double ri_hit = m.refractive_index;
         double ri_other = C.other_leaf >= 0 ? S.materials[S.leaves[C.other_leaf].material].refractive_index : 1.0;
         if (C.hit_inside) {
@@ -1211,7 +1257,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     SQ.distance = magnitude(v);
     SQ.found = false;
     Ray shadow_ray{over_point, normalize(v)};
-    traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG>, COUNT>(S, shadow_ray, SQ, st, cs);
+    traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM>, COUNT>(S, shadow_ray, SQ, st, cs);
     out_r = SQ.found ? ar : lr;
     out_g = SQ.found ? ag : lg;
     out_b = SQ.found ? ab : lb;
@@ -1388,6 +1434,7 @@ struct rt_scene {
   double build_seconds = 0;
   int stack_need = 1;
   bool has_csg = false;
+  bool uniform_nodes = false;  // large hierarchy: kernels with the scalar path for nodes a whole wave visits
   int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
   GenBuf gens[MAX_GENERATIONS + 1];
   uint32_t* d_counts = nullptr;           // [gen]: length of the next generation
@@ -1903,7 +1950,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     return fail(RT_ERR_UNSUPPORTED, "scene hierarchy is deeper than the traversal stack");
   if (getenv("RT_AMD_DEBUG")) {
     int occ = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_generation<STACK_SMALL, false, 0, false>, BLOCK, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_generation<STACK_SMALL, false, 0, false, false>, BLOCK, 0);
     fprintf(stderr, "[rt_amd] k_generation<%d> blocks of %d per CU (occupancy API): %d\n", STACK_SMALL, BLOCK, occ);
     fprintf(stderr, "[rt_amd] leaves=%d gates=%d nodes=%zu tris=%zu quads=%zu unbounded=%zu bands=%zu stack_need=%d\n", d->n_leaves,
             d->n_gates, b.bvh.nodes.size(), b.bvh.tri_order.size(), b.bvh.quad_order.size(), b.unbounded.size(), b.bands.size(),
@@ -2004,6 +2051,11 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((rc = upload(s, pats, &s->dev.patterns))) return rc;
   s->dev.root = root;
   s->dev.root_alt = b.bvh.alt(root);
+  // Measured: the scalar path for wave-uniform nodes pays off for hierarchies far beyond the 32 KB L1
+  // of a CU (1M-triangle mesh: -6 % frame time) and costs a few percent on small ones (12k triangles:
+  // +5 %), whose upper levels stay in L1 anyway.
+  s->uniform_nodes = b.bvh.nodes.size() >= 8192;
+  if (const char* e = getenv("RT_AMD_UNIFORM_NODES")) s->uniform_nodes = atoi(e) != 0;
   s->dev.n_unbounded = (int32_t)b.unbounded.size();
   s->dev.n_leaves = d->n_leaves;
   for (int a = 0; a < 3; a++) {
@@ -2183,16 +2235,16 @@ struct GenLaunch {
 
 constexpr unsigned CSG_LDS_BYTES = CSG_MAX_HITS * 3 * BLOCK * sizeof(uint32_t);
 
-template <int STACK, bool COUNT, bool CSG>
+template <int STACK, bool COUNT, bool CSG, bool UNIFORM = false>
 void launch_generation_mode(rt_scene* s, int mode, const GenLaunch& a) {
   dim3 grid(blocks_for(a.n)), block(BLOCK);
   static const unsigned env_lds = getenv("RT_AMD_EXTRA_LDS") ? (unsigned)atoi(getenv("RT_AMD_EXTRA_LDS")) : 0u;
   const unsigned extra_lds = (CSG ? CSG_LDS_BYTES : 0u) + env_lds;
 #define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_capacity, a.remaining, a.next_count, a.stats, a.cam, a.tiles, a.tiles_x, a.img
   switch (mode) {
-    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
-    case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1, CSG>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
-    default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2, CSG>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
+    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
+    case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
+    default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
   }
 #undef RT_GEN_ARGS
 }
@@ -2203,9 +2255,11 @@ void launch_generation(rt_scene* s, int mode, bool count, const GenLaunch& a) {
     else launch_generation_mode<64, false, true>(s, mode, a);
   } else if (pick_stack(s->stack_need) == STACK_SMALL) {
     if (count) launch_generation_mode<STACK_SMALL, true, false>(s, mode, a);
+    else if (s->uniform_nodes) launch_generation_mode<STACK_SMALL, false, false, true>(s, mode, a);
     else launch_generation_mode<STACK_SMALL, false, false>(s, mode, a);
   } else {
     if (count) launch_generation_mode<64, true, false>(s, mode, a);
+    else if (s->uniform_nodes) launch_generation_mode<64, false, false, true>(s, mode, a);
     else launch_generation_mode<64, false, false>(s, mode, a);
   }
 }
