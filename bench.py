@@ -27,6 +27,7 @@ from __graft_entry__ import load_package  # noqa: E402
 
 FP64_VALU_PEAK = 78.6e12  # MI355X vector FP64, FLOP/s (datasheet)
 HBM_PEAK = 8.0e12         # bytes/s (datasheet)
+L1_RETURN_PEAK = 256 * 64 * 2.4e9  # bytes/s: 64 B per clock per CU from the vector L1 to the registers
 
 # Algorithmic work of the generation kernel, from the traversal counters of one instrumented frame.
 # Operations (counted as the reference counts arithmetic: one per add / mul / compare-select, no FMA
@@ -194,6 +195,7 @@ def main():
         "kernel": "k_generation", "avg_launch_ms": avg_ms, "launches_per_frame": launches,
         "flops_per_launch": fl, "bytes_per_launch": by, "frac_fp64_valu": frac_valu, "frac_hbm": frac_hbm,
         "onchip_bytes_per_launch": onchip / launches, "onchip_GBps": onchip / launches / avg_s / 1e9,
+        "frac_l1_return": onchip / launches / avg_s / L1_RETURN_PEAK,
         "events_per_frame": events,
         "overlap": "consecutive frames run on two streams, so a launch shares the GPU with the tail or head of its "
                    "neighbour: avg_launch_ms is longer than a lone launch (about 0.17 ms) while frames complete faster",
@@ -201,7 +203,9 @@ def main():
                 "which counts an FMA as two; the path is compiled without contraction to match the reference bit for "
                 "bit, so half of that is reachable) and HBM (8 TB/s). bytes_per_launch is the unavoidable HBM traffic "
                 "(scene once, pixels, ray records); the per-visit record fetches of the %.1f MB scene are served by "
-                "L1 / L2 and listed as onchip_bytes" % (foot["scene_bytes"] / 1e6),
+                "L1 / L2 and listed as onchip_bytes; they are priced against the L1 -> register return path "
+                "(64 B / clock / CU, 39 TB/s), which the counters show as the busiest unit (TD busy 76 %%): a wave "
+                "load returns 1 KB whatever its lanes address" % (foot["scene_bytes"] / 1e6),
     })
 
     if rank != 0:
