@@ -290,3 +290,47 @@ def test_parallel_render_writes_the_reference_ppm(pkg, root, tmp_path):
         assert a.shape == b.shape and np.abs(a - b).max() <= 1 and (a != b).sum() <= 5
     bad = subprocess.run([cli, "-s", os.path.join(root, "absent.json"), "-o", str(out2)], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0
+
+
+def test_c_abi_rejects_bad_arguments_and_releases_memory(pkg, root):
+    """Error behaviour of the boundary: negative status plus a message, never a crash; and a scene
+    gives its device memory back."""
+    import ctypes as C
+    import torch
+
+    amd, _ = pkg.libraries()
+    gpu, _ = load_pair(pkg, root, "teapot", (64, 36))
+    cam = gpu.camera()
+    dev = gpu._dev()
+    st = pkg.RtStats()
+    buf = torch.zeros(64 * 36 * 3, dtype=torch.uint8, device="cuda:0")
+
+    def render(camera=cam, part=0, n_parts=1, flags=0, scene=dev):
+        return amd.rt_render(scene, C.byref(camera), part, n_parts, flags, C.c_void_p(buf.data_ptr()), None, None, C.byref(st))
+
+    assert render() == 0
+    assert render(part=2, n_parts=2) == -1 and b"part" in amd.rt_last_error()
+    assert render(n_parts=0) == -1
+    assert render(scene=None) == -1
+    empty = pkg.RtCamera.from_buffer_copy(cam)
+    empty.hsize = 0
+    assert render(camera=empty) == -1 and b"empty canvas" in amd.rt_last_error()
+    skew = pkg.RtCamera.from_buffer_copy(cam)
+    skew.inv[12] = 0.5  # a projective camera matrix
+    assert render(camera=skew) == -2
+    assert amd.rt_render(dev, C.byref(cam), 0, 1, 4, None, None, None, C.byref(st)) == -1  # compact without rgb8
+    assert amd.rt_scene_wait(None, C.byref(st)) == -1
+    assert amd.rt_download(dev, None, None, 16, None) == -1
+    assert render() == 0  # still usable after the refusals
+
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    path = os.path.join(root, "scenes", "teapot.json")
+    for _ in range(20):
+        s = pkg.Scene.from_file(path, base_dir=root, device=0)
+        s.set_canvas(64, 36)
+        s.render(rgb64=False, hit_leaf=False)
+        s.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, "device memory leaked by create / destroy"
