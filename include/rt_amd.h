@@ -183,7 +183,8 @@ typedef struct rt_scene rt_scene;
 enum {
   RT_FLAG_COUNTERS = 1, /* run the instrumented kernels and fill the work counters */
   RT_FLAG_ASYNC = 2,    /* rt_render only: enqueue the frame and return; see rt_scene_wait */
-  RT_FLAG_COMPACT = 4   /* rt_render only: rgb8_dev receives just this part's pixels, see rt_render */
+  RT_FLAG_COMPACT = 4,  /* rt_render only: rgb8_dev receives just this part's pixels, see rt_render */
+  RT_FLAG_BANDS = 8     /* rt_render only: parts are bands of 32 pixel rows, band b belongs to part b % n_parts */
 };
 
 const char* rt_last_error(void);
@@ -201,7 +202,8 @@ void rt_scene_destroy(rt_scene* scene);
 int rt_scene_footprint(const rt_scene* scene, uint64_t* scene_bytes, double* build_seconds);
 
 /* `parallel_render` without the file write: renders part `part` of `n_parts`
- * (interleaved 32x32 pixel tiles; part 0 of 1 is the whole image).  Outputs
+ * (interleaved 32x32 pixel tiles, tile (tx, ty) belongs to part (tx + ty) % n_parts, or with
+ * RT_FLAG_BANDS whole rows of tiles, row ty to part ty % n_parts; part 0 of 1 is the whole image).  Outputs
  * are full-size W*H images in which only this part's pixels are written; any
  * of them may be NULL.  rgb8: the quantised bytes of `Canvas::save`
  * (ceil(clamp(c*255)), src/canvas.rs:60-62); rgb64: the f64 colours;
@@ -238,7 +240,21 @@ int rt_scene_stream(rt_scene* scene, void** hip_stream);
 int rt_download(rt_scene* scene, const void* src_dev, void* dst_host, uint64_t bytes, void* after_stream);
 int rt_scene_copy_stream(rt_scene* scene, void** hip_stream);
 
-/* Same, into host buffers (the library stages through device memory). */
+/* The same for `rows` pieces of row_bytes bytes that lie `pitch` bytes apart in both buffers.  With
+ * RT_FLAG_BANDS a part of a frame is exactly that: bands of 32 pixel rows (row_bytes = 32 * width * 3),
+ * n_parts bands apart, so every GPU of a node moves its own bands over its own PCIe link straight
+ * into one host frame (shared, page-locked memory) and no GPU-to-GPU exchange is needed. */
+int rt_download_2d(rt_scene* scene, const void* src_dev, void* dst_host, uint64_t row_bytes, uint64_t rows,
+                   uint64_t pitch, void* after_stream);
+
+/* Page-locked host memory usable from every GPU of the process (NULL when it cannot be had): frames
+ * in it are filled by DMA at full PCIe speed.  The reference's canvas is a plain Vec (src/canvas.rs:22-28). */
+void* rt_host_alloc(uint64_t bytes);
+void rt_host_free(void* p);
+
+/* Same, into host buffers (the library stages through device memory).  With RT_FLAG_BANDS only the
+ * part's own bands are copied to the host buffers, so the parts of one frame, rendered by different
+ * GPUs from different threads, can be given the same buffers and fill them without overlap. */
 int rt_render_host(rt_scene* scene, const rt_camera* camera, int part, int n_parts, uint32_t flags,
                    uint8_t* rgb8, double* rgb64, int32_t* hit_leaf, rt_stats* stats);
 

@@ -7,7 +7,7 @@ directory: ``lib/librt_amd.so`` (HIP kernels + the C ABI of include/rt_amd.h)
 and ``lib/librt_host.so`` (scene JSON, OBJ, flattening, PPM).  This package is
 a thin ctypes binding; there is no CPU fallback: a missing library raises.
 """
-from . import tiles  # noqa: F401
+from . import bindings, tiles  # noqa: F401
 from .bindings import (  # noqa: F401
     RtCamera,
     RtStats,

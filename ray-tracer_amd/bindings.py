@@ -17,6 +17,7 @@ _LIBDIR = os.path.join(_HERE, "lib")
 RT_FLAG_COUNTERS = 1
 RT_FLAG_ASYNC = 2
 RT_FLAG_COMPACT = 4
+RT_FLAG_BANDS = 8
 
 
 class RtError(RuntimeError):
@@ -91,6 +92,7 @@ def libraries():
     amd.rt_scene_stream.argtypes = [vp, C.POINTER(vp)]
     amd.rt_scene_copy_stream.argtypes = [vp, C.POINTER(vp)]
     amd.rt_download.argtypes = [vp, vp, vp, u64, vp]
+    amd.rt_download_2d.argtypes = [vp, vp, vp, u64, u64, u64, vp]
     amd.rt_render_host.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
     amd.rt_ray_for_pixel.argtypes = [vp, C.POINTER(RtCamera), u64, vp, vp]
     amd.rt_color_at.argtypes = [vp, u64, vp, i32, u32, vp, vp, C.POINTER(RtStats)]
@@ -240,12 +242,13 @@ class Scene:
         return out, st
 
     def render_device(self, rgb8_ptr=0, rgb64_ptr=0, hit_leaf_ptr=0, part=0, n_parts=1, counters=False, wait=True,
-                      compact=False):
+                      compact=False, bands=False):
         """rt_render into device buffers given by address (e.g. torch tensor .data_ptr()).  With
         wait=False the frame is only enqueued (RT_FLAG_ASYNC); collect with wait()."""
         cam = self.camera()
         st = RtStats()
-        flags = (RT_FLAG_COUNTERS if counters else 0) | (0 if wait else RT_FLAG_ASYNC) | (RT_FLAG_COMPACT if compact else 0)
+        flags = ((RT_FLAG_COUNTERS if counters else 0) | (0 if wait else RT_FLAG_ASYNC) | (RT_FLAG_COMPACT if compact else 0)
+                 | (RT_FLAG_BANDS if bands else 0))
         self._check(self._amd.rt_render(self._dev(), C.byref(cam), part, n_parts, flags,
                                         C.c_void_p(rgb8_ptr or None), C.c_void_p(rgb64_ptr or None),
                                         C.c_void_p(hit_leaf_ptr or None), C.byref(st)))
@@ -262,6 +265,11 @@ class Scene:
         now on after_stream (address of a hipStream_t; 0 = the scene's render stream)."""
         self._check(self._amd.rt_download(self._dev(), C.c_void_p(src_ptr), C.c_void_p(dst_ptr), nbytes,
                                           C.c_void_p(after_stream or None)))
+
+    def download_2d(self, src_ptr, dst_ptr, row_bytes, rows, pitch, after_stream=0):
+        """rt_download_2d: `rows` pieces of row_bytes bytes, pitch bytes apart in both buffers."""
+        self._check(self._amd.rt_download_2d(self._dev(), C.c_void_p(src_ptr), C.c_void_p(dst_ptr), row_bytes, rows, pitch,
+                                             C.c_void_p(after_stream or None)))
 
     def copy_stream_ptr(self):
         p = C.c_void_p()

@@ -2190,6 +2190,19 @@ extern "C" int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int
   return missing;
 }
 
+extern "C" void* rt_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+extern "C" void rt_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 extern "C" int rt_scene_footprint(const rt_scene* s, uint64_t* scene_bytes, double* build_seconds) {
   if (!s) return fail(RT_ERR_INVALID, "null scene");
   if (scene_bytes) *scene_bytes = s->scene_bytes;
@@ -2475,7 +2488,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   HIP_TRY(hipSetDevice(s->device));
   if (stats) memset(stats, 0, sizeof(*stats));
   uint32_t tiles_x = (camera->hsize + TILE - 1) / TILE, tiles_y = (camera->vsize + TILE - 1) / TILE;
-  const uint32_t key[4] = {camera->hsize, camera->vsize, (uint32_t)part, (uint32_t)n_parts};
+  const bool bands = (flags & RT_FLAG_BANDS) != 0;
+  const uint32_t key[4] = {camera->hsize, camera->vsize, (uint32_t)part | (bands ? 0x80000000u : 0u), (uint32_t)n_parts};
   if (memcmp(key, s->tiles_key, sizeof(key)) != 0) {
     int rcw = collect_all(s);  // frames in flight still read the current tile table
     if (rcw) return rcw;
@@ -2483,7 +2497,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
     s->h_tiles.clear();
     for (uint32_t ty = 0; ty < tiles_y; ty++)
       for (uint32_t tx = 0; tx < tiles_x; tx++)
-        if ((int)((tx + ty) % (uint32_t)n_parts) == part) s->h_tiles.push_back(ty * tiles_x + tx);
+        if ((int)(((bands ? 0u : tx) + ty) % (uint32_t)n_parts) == part) s->h_tiles.push_back(ty * tiles_x + tx);
     if (s->tiles_capacity < s->h_tiles.size()) {
       if (s->d_tiles) {
         HIP_TRY(hipStreamSynchronize(s->stream));
@@ -2552,6 +2566,19 @@ extern "C" int rt_scene_copy_stream(rt_scene* s, void** hip_stream) {
   return RT_OK;
 }
 
+extern "C" int rt_download_2d(rt_scene* s, const void* src_dev, void* dst_host, uint64_t row_bytes, uint64_t rows,
+                              uint64_t pitch, void* after_stream) {
+  if (!s || (row_bytes && rows && (!src_dev || !dst_host))) return fail(RT_ERR_INVALID, "null argument");
+  if (pitch < row_bytes) return fail(RT_ERR_INVALID, "pitch smaller than a row");
+  HIP_TRY(hipSetDevice(s->device));
+  if (row_bytes == 0 || rows == 0) return RT_OK;
+  hipStream_t after = after_stream ? (hipStream_t)after_stream : s->last_stream;
+  HIP_TRY(hipEventRecord(s->copy_order, after));
+  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order, 0));
+  HIP_TRY(hipMemcpy2DAsync(dst_host, pitch, src_dev, pitch, row_bytes, rows, hipMemcpyDeviceToHost, s->copy_stream));
+  return RT_OK;
+}
+
 extern "C" int rt_download(rt_scene* s, const void* src_dev, void* dst_host, uint64_t bytes, void* after_stream) {
   if (!s || (bytes && (!src_dev || !dst_host))) return fail(RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(s->device));
@@ -2580,6 +2607,22 @@ extern "C" int rt_render_host(rt_scene* s, const rt_camera* camera, int part, in
   rc = rt_render(s, camera, part, n_parts, flags & ~(uint32_t)(RT_FLAG_ASYNC | RT_FLAG_COMPACT), rgb8 ? (uint8_t*)base : nullptr,
                  rgb64 ? (double*)(base + off64) : nullptr, hit_leaf ? (int32_t*)(base + offl) : nullptr, stats);
   if (rc) return rc;
+  if ((flags & RT_FLAG_BANDS) && n_parts > 1) {
+    // only this part's bands of 32 rows go to the host images, so the parts of one frame can share them
+    const size_t rows_total = camera->vsize, w = camera->hsize;
+    for (size_t y0 = (size_t)part * TILE; y0 < rows_total; y0 += (size_t)n_parts * TILE) {
+      const size_t rows = std::min<size_t>(TILE, rows_total - y0), px = y0 * w, n = rows * w;
+      if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8 + px * 3, base + px * 3, n * 3, hipMemcpyDeviceToHost, s->stream));
+      if (rgb64)
+        HIP_TRY(hipMemcpyAsync(rgb64 + px * 3, base + off64 + px * 3 * sizeof(double), n * 3 * sizeof(double),
+                               hipMemcpyDeviceToHost, s->stream));
+      if (hit_leaf)
+        HIP_TRY(hipMemcpyAsync(hit_leaf + px, base + offl + px * sizeof(int32_t), n * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return RT_OK;
+  }
   if (rgb8) HIP_TRY(hipMemcpy(rgb8, base, b8, hipMemcpyDeviceToHost));
   if (rgb64) HIP_TRY(hipMemcpy(rgb64, base + off64, b64, hipMemcpyDeviceToHost));
   if (hit_leaf) HIP_TRY(hipMemcpy(hit_leaf, base + offl, bl, hipMemcpyDeviceToHost));

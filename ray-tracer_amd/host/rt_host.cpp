@@ -951,12 +951,25 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
   rt_scene_desc desc = flat.desc();
   rt_camera cam = camera.describe();
   size_t np = camera.hsize * camera.vsize;
-  std::vector<std::vector<uint8_t>> parts(jobs, std::vector<uint8_t>(np * 3));
+  // One frame for all GPUs: part k is the bands of 32 pixel rows k, k + jobs, ... and every worker
+  // copies exactly its bands into the frame, so the pieces need no merging afterwards.
+  struct Frame {
+    uint8_t* p = nullptr;
+    bool pinned = false;
+    ~Frame() {
+      if (pinned) rt_host_free(p);
+      else free(p);
+    }
+  } frame;
+  frame.p = (uint8_t*)rt_host_alloc(np * 3);
+  frame.pinned = frame.p != nullptr;
+  if (!frame.p) frame.p = (uint8_t*)malloc(std::max<size_t>(np * 3, 1));
+  if (!frame.p) throw std::bad_alloc();
   std::vector<std::string> errors(jobs);
   auto worker = [&](size_t k) {
     rt_scene* sc = nullptr;
     if (rt_scene_create(&desc, (int)k, &sc) != RT_OK ||
-        rt_render_host(sc, &cam, (int)k, (int)jobs, 0, parts[k].data(), nullptr, nullptr, nullptr) != RT_OK)
+        rt_render_host(sc, &cam, (int)k, (int)jobs, RT_FLAG_BANDS, frame.p, nullptr, nullptr, nullptr) != RT_OK)
       errors[k] = rt_last_error();
     rt_scene_destroy(sc);
   };
@@ -966,15 +979,7 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
   for (auto& t : threads) t.join();
   for (const std::string& e : errors)
     if (!e.empty()) throw std::runtime_error(e);
-  // framebuffer gather: every GPU wrote only the 32x32 tiles with (tx + ty) % jobs == its index
-  std::vector<uint8_t>& image = parts[0];
-  const size_t T = 32;
-  for (size_t y = 0; y < camera.vsize; y++)
-    for (size_t x = 0; x < camera.hsize; x++) {
-      size_t owner = (x / T + y / T) % jobs;
-      if (owner) memcpy(&image[(y * camera.hsize + x) * 3], &parts[owner][(y * camera.hsize + x) * 3], 3);
-    }
-  std::string ppm = ppm_encode(camera.hsize, camera.vsize, image.data());
+  std::string ppm = ppm_encode(camera.hsize, camera.vsize, frame.p);
   std::ofstream of(out_path, std::ios::binary);
   if (!of) throw Panic("could not create output file " + out_path);
   of.write(ppm.data(), (std::streamsize)ppm.size());

@@ -45,6 +45,27 @@ def compact_pixel_index(width, height, part, n_parts, device="cpu", outside=-1):
     return idx.reshape(-1).to(device)
 
 
+def part_bands(height, part, n_parts):
+    """Row ranges [(y0, y1), ...] of the bands of 32 pixel rows that belong to `part` under
+    RT_FLAG_BANDS (band b belongs to part b % n_parts)."""
+    n_bands = (height + TILE - 1) // TILE
+    return [(b * TILE, min(height, (b + 1) * TILE)) for b in range(part, n_bands, n_parts)]
+
+
+def download_bands(scene, frame_ptr, host_ptr, width, height, part, n_parts, after_stream=0):
+    """Enqueues the copies of this part's bands from a full-size device frame to a full-size host frame."""
+    band_bytes = TILE * width * 3
+    bands = part_bands(height, part, n_parts)
+    full = [b for b in bands if b[1] - b[0] == TILE]
+    if full:
+        off = full[0][0] * width * 3
+        scene.download_2d(frame_ptr + off, host_ptr + off, band_bytes, len(full), n_parts * band_bytes, after_stream)
+    for y0, y1 in bands:
+        if y1 - y0 != TILE:  # the last band of an image whose height is not a multiple of 32
+            off = y0 * width * 3
+            scene.download(frame_ptr + off, host_ptr + off, (y1 - y0) * width * 3, after_stream)
+
+
 class FrameGather:
     """Collects the parts of a frame on rank 0.
 

@@ -334,3 +334,54 @@ def test_c_abi_rejects_bad_arguments_and_releases_memory(pkg, root):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, "device memory leaked by create / destroy"
+
+
+@pytest.mark.parametrize("size,n_parts", [((200, 112), 3), ((1920, 1080), 8), ((70, 50), 2)])
+def test_band_parts_assemble_in_one_host_frame(pkg, root, size, n_parts):
+    """RT_FLAG_BANDS + rt_download_2d, the multi-GPU path of bench.py with all parts on one GPU: every
+    part copies its own bands of 32 rows into one page-locked host frame."""
+    import torch
+
+    w, h = size
+    gpu, _ = load_pair(pkg, root, "teapot", size)
+    want, st_whole = gpu.render(rgb64=False, hit_leaf=False)
+    host = torch.zeros((h, w, 3), dtype=torch.uint8).pin_memory()
+    rows = 0
+    primary = 0
+    for part in range(n_parts):
+        dev = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+        st = gpu.render_device(rgb8_ptr=dev.data_ptr(), part=part, n_parts=n_parts, bands=True)
+        primary += st.primary
+        pkg.tiles.download_bands(gpu, dev.data_ptr(), host.data_ptr(), w, h, part, n_parts)
+        gpu.wait()
+        mine = pkg.tiles.part_bands(h, part, n_parts)
+        rows += sum(y1 - y0 for y0, y1 in mine)
+        written = torch.zeros(h, dtype=torch.bool)
+        for y0, y1 in mine:
+            written[y0:y1] = True
+        assert int(dev.cpu()[~written].sum()) == 0  # a part writes its own bands only
+    assert rows == h and primary == st_whole.primary
+    assert np.array_equal(host.numpy(), want["rgb8"])
+
+
+def test_render_host_with_bands_fills_shared_buffers(pkg, root):
+    """rt_render_host + RT_FLAG_BANDS: the parts of a frame write disjoint bands of the same host
+    buffers (what the C++ parallel_render does with one thread per GPU)."""
+    import ctypes as C
+
+    amd, _ = pkg.libraries()
+    gpu, _ = load_pair(pkg, root, "glass", (100, 70))
+    want, st_whole = gpu.render()
+    cam = gpu.camera()
+    rgb8 = np.zeros((70, 100, 3), np.uint8)
+    rgb64 = np.zeros((70, 100, 3), np.float64)
+    leaf = np.full((70, 100), -7, np.int32)
+    rays = 0
+    for part in range(3):
+        st = pkg.RtStats()
+        rc = amd.rt_render_host(gpu._dev(), C.byref(cam), part, 3, pkg.bindings.RT_FLAG_BANDS, rgb8.ctypes.data_as(C.c_void_p),
+                                rgb64.ctypes.data_as(C.c_void_p), leaf.ctypes.data_as(C.c_void_p), C.byref(st))
+        assert rc == 0, amd.rt_last_error()
+        rays += st.rays
+    assert rays == st_whole.rays
+    assert np.array_equal(rgb8, want["rgb8"]) and np.array_equal(rgb64, want["rgb64"]) and np.array_equal(leaf, want["hit_leaf"])

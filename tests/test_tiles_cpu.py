@@ -75,3 +75,14 @@ def test_two_rank_gather_rebuilds_the_frame():
         p.join(120)
         assert p.exitcode == 0
     assert out.get(timeout=5) is True
+
+
+def test_bands_partition_the_rows(pkg):
+    for h, n in [(1080, 8), (1080, 1), (31, 2), (64, 3), (100, 5)]:
+        seen = np.zeros(h, int)
+        for p in range(n):
+            for y0, y1 in pkg.tiles.part_bands(h, p, n):
+                assert y0 % 32 == 0 and (y1 - y0 == 32 or y1 == h)
+                assert (y0 // 32) % n == p
+                seen[y0:y1] += 1
+        assert (seen == 1).all()
