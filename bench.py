@@ -44,6 +44,9 @@ BYTES_PIXEL = 3
 RECORD_BYTES = 13 * 8 + 4 * 4  # one ray record of a generation buffer
 
 
+DEPTH = 4  # frames in flight: device frames, host frames and the library's frame slots
+
+
 def kernel_work(st, scene_bytes):
     nv = st.node_visits + st.shadow_node_visits
     tt = st.tri_tests + st.shadow_tri_tests
@@ -67,6 +70,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "teapot.json"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-download", action="store_true",
+                    help="profiling aid: leave the frames in HBM (under rocprofv3 the runtime turns the DMA copies "
+                         "into copy kernels that share the GPU with the render kernel and stretch it)")
     ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline renders every n-th pixel of every n-th row")
     args = ap.parse_args()
 
@@ -99,11 +105,11 @@ def main():
     # own stream while frame k + 1 renders, so the framebuffer of every frame still reaches the host
     # inside the timed region but off the critical path.  With several ranks every rank renders its
     # tiles in the compact layout and rank 0 gathers them (one RCCL gather + one indexed copy).
-    gather = pkg.tiles.FrameGather(W, H, device, rank, world)
-    frames = [torch.zeros((H, W, 3), dtype=torch.uint8, device=device) for _ in range(2)] if world == 1 else None
-    host_frames = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)] if rank == 0 else None
+    gather = pkg.tiles.FrameGather(W, H, device, rank, world, depth=DEPTH)
+    frames = [torch.zeros((H, W, 3), dtype=torch.uint8, device=device) for _ in range(DEPTH)] if world == 1 else None
+    host_frames = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(DEPTH)] if rank == 0 else None
     copy_stream = torch.cuda.ExternalStream(scene.copy_stream_ptr(), device=device)  # the library's copy stream
-    buffer_free = [torch.cuda.Event() for _ in range(2)]
+    buffer_free = [torch.cuda.Event() for _ in range(DEPTH)]
     stream_objects = {}
 
     def render_stream():  # the library stream the last frame went to
@@ -117,20 +123,21 @@ def main():
     def step():
         # Frames are enqueued, not waited for (the scene spawns no rays, so a frame is one kernel):
         # render k + 1 runs while frame k is gathered and copied; the streams are ordered by events.
-        k = step_no[0] % 2
+        k = step_no[0] % DEPTH
         step_no[0] += 1
-        buffer_free[k].synchronize()  # frame k - 2 has left these buffers (at most two frames in flight)
+        buffer_free[k].synchronize()  # frame k - DEPTH has left these buffers (at most DEPTH frames in flight)
         if world == 1:
             frame = frames[k]
             scene.render_device(rgb8_ptr=frame.data_ptr(), wait=False)
-            scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel())  # framebuffer on the host
+            if not args.no_download:
+                scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel())  # framebuffer on the host
             buffer_free[k].record(copy_stream)
             return
         else:
             scene.render_device(rgb8_ptr=gather.mine[k].data_ptr(), part=rank, n_parts=world, wait=False, compact=True)
             torch.cuda.current_stream().wait_stream(render_stream())
             frame = gather(k)  # rank 0: the whole frame
-        if rank == 0:
+        if rank == 0 and not args.no_download:
             scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel(),
                            after_stream=torch.cuda.current_stream().cuda_stream)
             buffer_free[k].record(copy_stream)
@@ -143,7 +150,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(8 + args.warmup):  # 8 priming frames: first launches load code objects and grow runtime pools
+    for _ in range(64 + args.warmup):  # 64 priming frames: first launches load code objects and grow runtime pools
         step()
     scene.wait()
     sync()
@@ -197,8 +204,9 @@ def main():
         "onchip_bytes_per_launch": onchip / launches, "onchip_GBps": onchip / launches / avg_s / 1e9,
         "frac_l1_return": onchip / launches / avg_s / L1_RETURN_PEAK,
         "events_per_frame": events,
-        "overlap": "consecutive frames run on two streams, so a launch shares the GPU with the tail or head of its "
-                   "neighbour: avg_launch_ms is longer than a lone launch (about 0.17 ms) while frames complete faster",
+        "overlap": "up to four frames are in flight on two streams, so a launch shares the GPU with its neighbours: "
+                   "avg_launch_ms is longer than a lone launch (about 0.17 ms) while frames complete faster -- a lone "
+                   "launch leaves about a third of the wave slots empty",
         "note": "no dense contraction on this path, so no MFMA: the ceilings are vector FP64 (78.6 TFLOP/s datasheet, "
                 "which counts an FMA as two; the path is compiled without contraction to match the reference bit for "
                 "bit, so half of that is reachable) and HBM (8 TB/s). bytes_per_launch is the unavoidable HBM traffic "
@@ -257,6 +265,9 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "breakdown_ms": {"frame": elapsed / args.steps * 1e3, "generation_kernels": kernel_ms / args.steps},
+        "pipeline": {"frames_in_flight": DEPTH, "untimed_priming_frames": 64,
+                     "note": "frames are enqueued on two alternating streams and copied to the host by DMA on a third; "
+                             "a frame is waited for only when its buffers are needed again"},
         "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": foot["build_seconds"], "scene_bytes": foot["scene_bytes"]},
     }
     print(json.dumps(out))

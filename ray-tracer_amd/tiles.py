@@ -69,13 +69,13 @@ def download_bands(scene, frame_ptr, host_ptr, width, height, part, n_parts, aft
 class FrameGather:
     """Collects the parts of a frame on rank 0.
 
-    Every rank renders its part in the compact layout into `mine[k]` (k = 0 / 1, two buffers so that
+    Every rank renders its part in the compact layout into `mine[k]` (k < depth: several buffers so that
     frame n + 1 can be rendered while frame n is still being gathered); `__call__(k, frame)` gathers
     the buffers to rank 0 and, there, scatters them into the (H, W, 3) uint8 `frame` with one indexed
     copy.  With one rank nothing is exchanged: the frame is rendered in place.
     """
 
-    def __init__(self, width, height, device, rank, world, backend=None):
+    def __init__(self, width, height, device, rank, world, backend=None, depth=2):
         self.rank, self.world, self.device = rank, world, device
         self.width, self.height = width, height
         self.backend = backend or (dist.get_backend() if world > 1 else None)
@@ -85,15 +85,15 @@ class FrameGather:
         idx = [compact_pixel_index(width, height, p, world, outside=n_pix) for p in range(world)]
         self.slots = [int(i.numel()) for i in idx]
         n_max = max(self.slots)
-        self.mine = [torch.zeros((n_max, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.mine = [torch.zeros((n_max, 3), dtype=torch.uint8, device=device) for _ in range(depth)]
         if rank == 0:
             # one index for all parts, padded slots and out-of-image slots land on a spare row
             pad = torch.full((world, n_max), n_pix, dtype=torch.int64)
             for p in range(world):
                 pad[p, : self.slots[p]] = idx[p]
             self.index = pad.reshape(-1).to(device)
-            self.recv = [torch.zeros((world, n_max, 3), dtype=torch.uint8, device=device) for _ in range(2)]
-            self.canvas = [torch.zeros((n_pix + 1, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+            self.recv = [torch.zeros((world, n_max, 3), dtype=torch.uint8, device=device) for _ in range(depth)]
+            self.canvas = [torch.zeros((n_pix + 1, 3), dtype=torch.uint8, device=device) for _ in range(depth)]
 
     def frame(self, k):
         """(H, W, 3) view of buffer k on rank 0 after __call__(k)."""
