@@ -203,6 +203,8 @@ def main():
         "flops_per_launch": fl, "bytes_per_launch": by, "frac_fp64_valu": frac_valu, "frac_hbm": frac_hbm,
         "onchip_bytes_per_launch": onchip / launches, "onchip_GBps": onchip / launches / avg_s / 1e9,
         "frac_l1_return": onchip / launches / avg_s / L1_RETURN_PEAK,
+        # the same work over the time the GPU actually spends per launch when launches overlap (frame period)
+        "frac_fp64_valu_per_frame_period": flops / (elapsed / args.steps) / FP64_VALU_PEAK,
         "events_per_frame": events,
         "overlap": "up to four frames are in flight on two streams, so a launch shares the GPU with its neighbours: "
                    "avg_launch_ms is longer than a lone launch (about 0.17 ms) while frames complete faster -- a lone "
