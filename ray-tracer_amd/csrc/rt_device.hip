@@ -826,6 +826,8 @@ DEV uint32_t thread_in_block() { return BLOCK == 64 ? (uint32_t)__lane_id() : th
 // (shaded hits = shadow rays, reflection rays, refraction rays) so that the per-wave
 // adds do not all land on one address.
 constexpr int STAT_SLOTS = 64;
+constexpr int QUEUE_SEGMENTS = 64;
+constexpr int COUNT_WORDS = (MAX_GENERATIONS + 1) * QUEUE_SEGMENTS;  // queue counters of one frame
 constexpr int STAT_RAYS = 8;
 #ifdef RT_STAMPS
 // Diagnostic build: per-wave clock stamps between the sections of k_generation, summed per section.
@@ -978,6 +980,33 @@ DEV uint32_t wave_append(uint32_t* counter, bool mine) {
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// The rays a generation spawns are queued in QUEUE_SEGMENTS segments, each with its own counter and
+// its own stretch of `segcap` record slots (segment s holds slots [s * segcap, (s + 1) * segcap)): a
+// wave appends to segment (wave number % QUEUE_SEGMENTS).  One counter for all waves serialises the
+// returning atomics at one L2 address, about 10 ns each, which for a generation of half a million rays
+// (15 000 atomics) is more than the tracing itself takes.
+//
+// The next generation runs one thread per queued ray: thread i finds its segment and record slot from
+// the running sum of the segment counters.  Every lane of the wave must call this (it shuffles).
+DEV bool queue_slot(const uint32_t* counts, uint32_t segcap, uint32_t i, uint32_t& slot) {
+  static_assert(QUEUE_SEGMENTS == 64, "one segment counter per lane of a wave");
+  const uint32_t lane = thread_in_block() & 63u;
+  const uint32_t c = min(counts[lane], segcap);
+  uint32_t p = c;  // inclusive running sum over the segments
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    uint32_t v = __shfl_up(p, d, 64);
+    if (lane >= d) p += v;
+  }
+  uint32_t seg = 0;  // the number of segments that end at or before ray i, at most 63
+  for (uint32_t step = 32; step > 0; step >>= 1) {
+    uint32_t v = __shfl(p, (int)(seg + step - 1), 64);
+    if (v <= i) seg += step;
+  }
+  const uint32_t end = __shfl(p, (int)seg, 64), len = __shfl(c, (int)seg, 64);
+  slot = seg * segcap + (i - (end - len));
+  return i < end;
+}
+
 // reflect_dot_eye.powf(shininess) (src/light.rs:168).  A whole-number exponent up to 1024 (the
 // default material's is 200) is raised by repeated squaring: about ten multiplications, each
 // correctly rounded, so the result stays within a few ulps of the libm value; anything else goes
@@ -1071,9 +1100,9 @@ DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y
 #endif
 template <int STACK, bool COUNT, int MODE, bool CSG, bool UNIFORM>
 __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES_SPAWN)
-    k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_capacity, int remaining,
-                 uint32_t* next_count, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
-                 uint32_t tiles_x, ImageOut img) {
+    k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_segcap, int remaining,
+                 uint32_t* next_counts, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
+                 uint32_t tiles_x, ImageOut img, const uint32_t* queue_counts, uint32_t segcap) {
   __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
   LdsStack<STACK, BLOCK, CSG, UNIFORM> st;
   extern __shared__ uint32_t csg_lds[];  // CSG_MAX_HITS * 3 * BLOCK words when the scene has CSG operators, else nothing
@@ -1081,15 +1110,21 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
 #ifdef RT_STAMPS
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
+  // i: the thread's ray; rec: where the ray's record lives.  Camera rays and rays handed in by the
+  // caller are dense (rec == i, n of them); spawned rays are found through the segment counters the
+  // generation before left in queue_counts, and n only bounds the grid.
   const uint32_t i = blockIdx.x * BLOCK + thread_in_block();
+  uint32_t rec = i;
   bool active = i < n;
+  if (MODE == 2 && queue_counts) active = queue_slot(queue_counts, segcap, i, rec) && active;
+  const bool has_record = active;
   uint32_t px = 0, py = 0;
   Ray ray{v3(0, 0, 0), v3(0, 0, 1)};
   if (MODE != 2) {
     active = active && ray_pixel(tiles, tiles_x, cam, i, px, py);
     if (active) ray = camera_ray(cam, px, py);
   } else if (active) {
-    ray = load_ray(g, i);
+    ray = load_ray(g, rec);
   }
 
   Counters ct{}, cs{};
@@ -1221,28 +1256,32 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
   if (MODE != 0) {
     // next generation: one atomic per wave that has something to append
     uint32_t child_reflect = REF_NONE, child_refract = REF_NONE;
-    uint32_t ri = wave_append(next_count, want_reflect);
-    if (want_reflect && ri < next_capacity) {
+    // this wave's segment of the next generation's queue
+    const uint32_t seg = (blockIdx.x * (BLOCK / 64) + (thread_in_block() >> 6)) % QUEUE_SEGMENTS;
+    uint32_t ri = wave_append(next_counts + seg, want_reflect);
+    if (want_reflect && ri < next_segcap) {
+      ri += seg * next_segcap;
       next.ox[ri] = reflect_ray.o.x; next.oy[ri] = reflect_ray.o.y; next.oz[ri] = reflect_ray.o.z;
       next.dx[ri] = reflect_ray.d.x; next.dy[ri] = reflect_ray.d.y; next.dz[ri] = reflect_ray.d.z;
       child_reflect = ri;
     }
-    uint32_t ti = wave_append(next_count, want_refract);
-    if (want_refract && ti < next_capacity) {
+    uint32_t ti = wave_append(next_counts + seg, want_refract);
+    if (want_refract && ti < next_segcap) {
+      ti += seg * next_segcap;
       next.ox[ti] = refract_ray.o.x; next.oy[ti] = refract_ray.o.y; next.oz[ti] = refract_ray.o.z;
       next.dx[ti] = refract_ray.d.x; next.dy[ti] = refract_ray.d.y; next.dz[ti] = refract_ray.d.z;
       child_refract = ti;
     }
-    if (i < n) {
-      g.flags[i] = flags;
-      g.leaf[i] = leaf;
-      g.child_reflect[i] = child_reflect;
-      g.child_refract[i] = child_refract;
+    if (has_record) {
+      g.flags[rec] = flags;
+      g.leaf[rec] = leaf;
+      g.child_reflect[rec] = child_reflect;
+      g.child_refract[rec] = child_refract;
       if (hit) {
-        g.t[i] = Q.best_t;
-        g.reflective[i] = k_reflective;
-        g.transparency[i] = k_transparency;
-        g.reflectance[i] = reflectance;
+        g.t[rec] = Q.best_t;
+        g.reflective[rec] = k_reflective;
+        g.transparency[rec] = k_transparency;
+        g.reflectance[rec] = reflectance;
       }
     }
   }
@@ -1265,8 +1304,8 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
   RT_STAMP(3);  // shadow traversal
   if (MODE == 0) {
     write_pixel(img, cam.hsize, px, py, i, active, out_r, out_g, out_b, leaf);
-  } else if (i < n) {
-    g.cr[i] = out_r; g.cg[i] = out_g; g.cb[i] = out_b;
+  } else if (has_record) {
+    g.cr[rec] = out_r; g.cg[rec] = out_g; g.cb[rec] = out_b;
   }
 
   // ray statistics, one add per wave and kind, spread over STAT_SLOTS addresses
@@ -1285,9 +1324,16 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
 }
 
 // shade_hit's final expression (src/world.rs:236-245), children first.
-__global__ void __launch_bounds__(BLOCK) k_resolve(GenView g, uint32_t n, GenView next) {
+__global__ void __launch_bounds__(BLOCK)
+    k_resolve(GenView g, uint32_t n, GenView next, const uint32_t* queue_counts, uint32_t segcap) {
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
+  bool active = i < n;
+  if (queue_counts) {  // spawned rays: records found through the segment counters
+    uint32_t rec;
+    active = queue_slot(queue_counts, segcap, i, rec) && active;
+    i = rec;
+  }
+  if (!active) return;
   uint32_t flags = g.flags[i];
   if (!(flags & 1u)) return;
   uint32_t cr = g.child_reflect[i], cf = g.child_refract[i];
@@ -1434,10 +1480,16 @@ struct rt_scene {
   double build_seconds = 0;
   int stack_need = 1;
   bool has_csg = false;
+  // queue lengths per generation of the last multi-generation frame: the next frame is launched on them
+  // without asking the device after every generation
+  uint32_t hint[MAX_GENERATIONS + 2] = {0};  // [g]: the fullest queue segment of generation g
+  uint32_t hint_key[2] = {0, 0};             // n0 and remaining0 the hints belong to
+  bool hint_valid = false;
+  uint32_t holdoff = 0, holdoff_next = 1;  // frames to render exactly after a speculative frame did not fit
   bool uniform_nodes = false;  // large hierarchy: kernels with the scalar path for nodes a whole wave visits
   int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
   GenBuf gens[MAX_GENERATIONS + 1];
-  uint32_t* d_counts = nullptr;           // [gen]: length of the next generation
+  uint32_t* d_counts = nullptr;           // [gen][QUEUE_SEGMENTS]: rays queued for the next generation, per segment
   unsigned long long* d_stats = nullptr;  // STAT_WORDS counters
   uint32_t* h_counts = nullptr;           // pinned mirrors
   unsigned long long* h_stats = nullptr;
@@ -2063,9 +2115,9 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     s->dev.light_position[a] = d->light.position[a];
   }
 
-  HIP_TRY(hipMalloc((void**)&s->d_counts, (MAX_GENERATIONS + 1) * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc((void**)&s->d_counts, COUNT_WORDS * sizeof(uint32_t)));
   HIP_TRY(hipMalloc((void**)&s->d_stats, STAT_WORDS * sizeof(unsigned long long)));
-  HIP_TRY(hipHostMalloc((void**)&s->h_counts, (MAX_GENERATIONS + 1) * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_counts, COUNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&s->h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
   for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
   for (rt_scene::FrameSlot& f : s->slots) {
@@ -2235,15 +2287,17 @@ inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + BLOCK - 1) / BLO
 
 struct GenLaunch {
   GenView cur, next;
-  uint32_t n, next_capacity;
+  uint32_t n, next_segcap;  // threads to launch; record slots per segment of the next generation's queue
   int remaining;
-  uint32_t* next_count;
+  uint32_t* next_counts;    // QUEUE_SEGMENTS counters
   CameraDev cam;
   const uint32_t* tiles;
   uint32_t tiles_x;
   ImageOut img;
   unsigned long long* stats;
   hipStream_t stream;
+  const uint32_t* queue_counts = nullptr;  // the segment counters this generation's rays were queued under
+  uint32_t segcap = 0;                     // (null: the rays are dense, n of them)
 };
 
 constexpr unsigned CSG_LDS_BYTES = CSG_MAX_HITS * 3 * BLOCK * sizeof(uint32_t);
@@ -2253,7 +2307,7 @@ void launch_generation_mode(rt_scene* s, int mode, const GenLaunch& a) {
   dim3 grid(blocks_for(a.n)), block(BLOCK);
   static const unsigned env_lds = getenv("RT_AMD_EXTRA_LDS") ? (unsigned)atoi(getenv("RT_AMD_EXTRA_LDS")) : 0u;
   const unsigned extra_lds = (CSG ? CSG_LDS_BYTES : 0u) + env_lds;
-#define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_capacity, a.remaining, a.next_count, a.stats, a.cam, a.tiles, a.tiles_x, a.img
+#define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap
   switch (mode) {
     case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
     case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
@@ -2373,9 +2427,9 @@ int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
   a.cur = s->gens[0].view;
   a.next = s->gens[1].view;
   a.n = in.n0;
-  a.next_capacity = 0;
+  a.next_segcap = 0;
   a.remaining = 0;
-  a.next_count = s->d_counts;
+  a.next_counts = s->d_counts;
   a.cam = in.cam;
   a.tiles = in.tiles;
   a.tiles_x = in.tiles_x;
@@ -2394,53 +2448,189 @@ int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
   return RT_OK;
 }
 
+// Record slots per queue segment that can never overflow: the waves of a generation of n rays are dealt
+// to the segments round-robin and a wave spawns at most 64 * max_children rays.
+inline uint64_t safe_segcap(uint64_t n, uint32_t max_children) {
+  const uint64_t waves = (n + 63) / 64;
+  return (waves + QUEUE_SEGMENTS - 1) / QUEUE_SEGMENTS * 64 * max_children;
+}
+
+struct GenPlan {
+  uint32_t threads[MAX_GENERATIONS + 2] = {0};  // grid size of generation g (for g > 0 an upper bound when speculative)
+  uint32_t segcap[MAX_GENERATIONS + 2] = {0};   // record slots per queue segment of generation g (g > 0)
+};
+
+void fill_launch(rt_scene* s, const PipelineIn& in, const GenPlan& plan, int g, int max_gen, GenLaunch& a) {
+  a.cur = s->gens[g].view;
+  a.next = s->gens[g + 1].view;
+  a.n = plan.threads[g];
+  a.next_segcap = g < max_gen ? plan.segcap[g + 1] : 0;
+  a.remaining = g < max_gen ? std::max(in.remaining0 - g, 0) : 0;
+  a.next_counts = s->d_counts + g * QUEUE_SEGMENTS;
+  a.cam = in.cam;
+  a.tiles = in.tiles;
+  a.tiles_x = in.tiles_x;
+  a.img = in.img;
+  a.stats = s->d_stats;
+  a.stream = s->stream;
+  a.queue_counts = g > 0 ? s->d_counts + (g - 1) * QUEUE_SEGMENTS : nullptr;
+  a.segcap = plan.segcap[g];
+}
+
+void launch_resolve(rt_scene* s, const GenPlan& plan, int g) {
+  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(plan.threads[g])), dim3(BLOCK), 0, s->stream, s->gens[g].view,
+                     plan.threads[g], s->gens[g + 1].view,
+                     g > 0 ? s->d_counts + (g - 1) * QUEUE_SEGMENTS : (const uint32_t*)nullptr, plan.segcap[g]);
+}
+
+// The frame launched at once on twice the queue lengths of the frame before (scene->hint; unused room
+// costs waves that exit at once):
+// no host round trip between the generations; the kernels find their rays through the segment counters
+// on the device.  The counters come back in one copy at the end.  *fits = false when a segment
+// received more rays than it had room for: the frame's output is then unusable.
+// Sizes the generations from the hints and makes room for them; returns the last generation to launch.
+int plan_speculative(rt_scene* s, const PipelineIn& in, int max_gen, GenPlan& plan, int* last_out) {
+  plan.threads[0] = in.n0;
+  int last = 0;
+  for (int g = 1; g <= max_gen && s->hint[g] > 0; g++) {
+    const uint64_t safe = safe_segcap(plan.threads[g - 1], s->max_children);
+    const uint64_t want = 2 * (uint64_t)s->hint[g] + 256;
+    plan.segcap[g] = (uint32_t)std::min(safe, want);
+    plan.threads[g] = plan.segcap[g] * QUEUE_SEGMENTS;
+    last = g;
+  }
+  int rc;
+  for (int g = 0; g <= last + 1 && g <= MAX_GENERATIONS; g++)
+    if ((rc = ensure_gen(s, g, g == 0 ? in.n0 : (size_t)plan.segcap[g] * QUEUE_SEGMENTS))) return rc;
+  *last_out = last;
+  return RT_OK;
+}
+
+int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_stats* stats, bool* fits) {
+  GenPlan plan;
+  int last = 0, rc;
+  if ((rc = plan_speculative(s, in, max_gen, plan, &last))) return rc;
+  HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+  for (int g = 0; g <= last; g++) {
+    GenLaunch a;
+    fill_launch(s, in, plan, g, max_gen, a);
+    launch_generation(s, (g == 0 && in.camera) ? 1 : 2, false, a);
+  }
+  HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+  for (int g = last - 1; g >= 0; g--) launch_resolve(s, plan, g);
+  if (in.camera)
+    hipLaunchKernelGGL(k_output_image, dim3(blocks_for(in.n0)), dim3(BLOCK), 0, s->stream, s->gens[0].view, in.n0,
+                       in.cam, in.tiles, in.tiles_x, in.img);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                         s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *fits = true;
+  int true_last = 0;
+  for (int g = 1; g <= max_gen && *fits; g++) {  // counters [g - 1]: the rays queued for generation g
+    uint32_t fullest = 0;
+    for (int k = 0; k < QUEUE_SEGMENTS; k++) fullest = std::max(fullest, s->h_counts[(g - 1) * QUEUE_SEGMENTS + k]);
+    if (fullest > plan.segcap[g]) *fits = false;
+    if (fullest == 0) break;
+    true_last = g;
+  }
+  if (!*fits) return RT_OK;
+  for (int g = 1; g <= MAX_GENERATIONS + 1; g++) {
+    uint32_t fullest = 0;
+    if (g <= true_last)
+      for (int k = 0; k < QUEUE_SEGMENTS; k++) fullest = std::max(fullest, s->h_counts[(g - 1) * QUEUE_SEGMENTS + k]);
+    s->hint[g] = fullest;
+  }
+  if (stats) {
+    decode_stats(s->h_stats, stats);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    stats->kernel_ms = ms;
+    stats->kernel_launches = (uint64_t)true_last + 1;
+    stats->generations = (uint64_t)true_last + 1;
+  }
+  return RT_OK;
+}
+
 // Runs the generations, resolves colours back into generation 0 and, for camera
 // rays, writes the image.  Fills the device-side fields of stats.
 int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
   const bool count = (in.flags & RT_FLAG_COUNTERS) != 0;
-  HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), s->stream));
   int max_gen = std::min(std::max(in.remaining0, 0), RECURSION_DEPTH);
   if (s->max_children == 0) max_gen = 0;
   const bool direct = in.camera && max_gen == 0;  // every pixel is final after generation 0
-  if (max_gen > 0) HIP_TRY(hipMemsetAsync(s->d_counts, 0, (MAX_GENERATIONS + 1) * sizeof(uint32_t), s->stream));
-  uint32_t n[MAX_GENERATIONS + 2] = {0};
-  n[0] = in.n0;
+  static const bool no_speculation = getenv("RT_AMD_NO_SPECULATION") != nullptr;
+  const bool hinted = max_gen > 0 && !count && !no_speculation && s->hint_valid && s->hint_key[0] == in.n0 &&
+                      s->hint_key[1] == (uint32_t)in.remaining0;
+  if (hinted && s->holdoff > 0) {
+    s->holdoff--;
+  } else if (hinted) {
+    HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), s->stream));
+    bool fits = false;
+    int rc = run_speculative(s, in, max_gen, stats, &fits);
+    if (rc) return rc;
+    if (fits) {
+      s->holdoff_next = 1;
+      return RT_OK;
+    }
+    // start over, one generation at a time, and stay exact for a while: a frame that does not fit is
+    // rendered twice, and a camera that moves this fast will do it again
+    s->holdoff = s->holdoff_next;
+    s->holdoff_next = std::min(2 * s->holdoff_next, 64u);
+    static const bool debug = getenv("RT_AMD_DEBUG") != nullptr;
+    if (debug) fprintf(stderr, "[rt_amd] speculative frame did not fit; exact for the next %u frames\n", s->holdoff);
+  }
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), s->stream));
+  if (max_gen > 0) HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), s->stream));
+  GenPlan plan;
+  uint32_t fullest[MAX_GENERATIONS + 2] = {0};
+  plan.threads[0] = in.n0;
   int last = 0;
-  for (int g = 0; g <= max_gen && n[g] > 0; g++) {
+  for (int g = 0; g <= max_gen && plan.threads[g] > 0; g++) {
     last = g;
-    int remaining = in.remaining0 - g;
-    if (remaining < 0) remaining = 0;
-    uint64_t next_cap = (g < max_gen) ? (uint64_t)n[g] * (uint64_t)s->max_children : 0;
-    if (next_cap > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "too many secondary rays for one generation");
+    const uint64_t next_segcap = g < max_gen ? safe_segcap(plan.threads[g], s->max_children) : 0;
+    if (next_segcap * QUEUE_SEGMENTS > 0xFFFFFF00ull)
+      return fail(RT_ERR_UNSUPPORTED, "too many secondary rays for one generation");
+    plan.segcap[g + 1] = (uint32_t)next_segcap;
     int rc;
-    if (!direct && (rc = ensure_gen(s, g, n[g]))) return rc;
-    if ((rc = ensure_gen(s, g + 1, (size_t)next_cap))) return rc;
+    if (!direct && g == 0 && (rc = ensure_gen(s, 0, in.n0))) return rc;
+    if ((rc = ensure_gen(s, g + 1, (size_t)next_segcap * QUEUE_SEGMENTS))) return rc;
     GenLaunch a;
-    a.cur = s->gens[g].view;
-    a.next = s->gens[g + 1].view;
-    a.n = n[g];
-    a.next_capacity = (uint32_t)next_cap;
-    a.remaining = (g < max_gen) ? remaining : 0;
-    a.next_count = s->d_counts + g;
-    a.cam = in.cam;
-    a.tiles = in.tiles;
-    a.tiles_x = in.tiles_x;
-    a.img = in.img;
-    a.stats = s->d_stats;
-    a.stream = s->stream;
+    fill_launch(s, in, plan, g, max_gen, a);
     int mode = (g == 0 && in.camera) ? (direct ? 0 : 1) : 2;
     HIP_TRY(hipEventRecord(s->ev[g * 2 + 0], s->stream));
     launch_generation(s, mode, count, a);
     HIP_TRY(hipEventRecord(s->ev[g * 2 + 1], s->stream));
     if (g < max_gen) {
-      HIP_TRY(hipMemcpyAsync(s->h_counts + g, s->d_counts + g, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+      uint32_t* h = s->h_counts + g * QUEUE_SEGMENTS;
+      HIP_TRY(hipMemcpyAsync(h, s->d_counts + g * QUEUE_SEGMENTS, QUEUE_SEGMENTS * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             s->stream));
       HIP_TRY(hipStreamSynchronize(s->stream));
-      n[g + 1] = std::min<uint32_t>(s->h_counts[g], (uint32_t)next_cap);
+      uint64_t total = 0;
+      for (int k = 0; k < QUEUE_SEGMENTS; k++) {
+        total += std::min<uint32_t>(h[k], (uint32_t)next_segcap);
+        fullest[g + 1] = std::max(fullest[g + 1], h[k]);
+      }
+      plan.threads[g + 1] = (uint32_t)total;
     }
+#ifdef RT_STAMPS
+    {
+      static unsigned long long before[STAMP_WORDS];
+      if (g == 0) memset(before, 0, sizeof before);
+      HIP_TRY(hipMemcpy(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      const unsigned long long* t = s->h_stats + STAT_RAYS + 3 * STAT_SLOTS;
+      double d[STAMP_WORDS], sum = 0;
+      for (int k = 0; k < STAMP_WORDS; k++) { d[k] = (double)(t[k] - before[k]); before[k] = t[k]; }
+      for (int k = 0; k < 5; k++) sum += d[k];
+      const double waves = (double)blocks_for(plan.threads[g]) * (BLOCK / 64);
+      fprintf(stderr, "[rt_amd] generation %d rays %u: ticks per wave %.0f | raygen %.3f closest %.3f shade %.3f shadow %.3f output %.3f\n",
+              g, plan.threads[g], sum / waves, d[0] / sum, d[1] / sum, d[2] / sum, d[3] / sum, d[4] / sum);
+    }
+#endif
   }
-  for (int g = last - 1; g >= 0; g--)
-    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n[g])), dim3(BLOCK), 0, s->stream, s->gens[g].view, n[g],
-                       s->gens[g + 1].view);
+  for (int g = last - 1; g >= 0; g--) launch_resolve(s, plan, g);
   if (in.camera && !direct)
     hipLaunchKernelGGL(k_output_image, dim3(blocks_for(in.n0)), dim3(BLOCK), 0, s->stream, s->gens[0].view, in.n0,
                        in.cam, in.tiles, in.tiles_x, in.img);
@@ -2448,6 +2638,17 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                          s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (max_gen > 0) {
+    for (int g = 0; g <= MAX_GENERATIONS + 1; g++) s->hint[g] = fullest[g];
+    s->hint_key[0] = in.n0;
+    s->hint_key[1] = (uint32_t)in.remaining0;
+    s->hint_valid = true;
+    if (!count && !no_speculation) {  // room for the next frame's queues now, not inside that frame
+      GenPlan next_plan;
+      int next_last = 0, rc;
+      if ((rc = plan_speculative(s, in, max_gen, next_plan, &next_last))) return rc;
+    }
+  }
   if (stats) {
     decode_stats(s->h_stats, stats);
     stats->kernel_ms = 0;

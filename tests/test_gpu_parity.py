@@ -81,6 +81,32 @@ def test_rendering_twice_is_bit_identical(pkg, root):
     assert np.array_equal(a["rgb64"], b["rgb64"]) and np.array_equal(a["rgb8"], b["rgb8"])
 
 
+def test_frames_launched_on_the_last_frames_ray_counts(pkg, root):
+    """After its first frame a scene with secondary rays launches all generations at once, sized by the
+    ray counts of the frame before.  A camera that moves a little stays inside the margin, a camera that
+    turns from empty space to the glass does not and the frame is redone: either way the result must be
+    the one a fresh scene (which has no counts to go on) computes."""
+    w, h, fov = 192, 108, 1.0472
+    cams = [((0.0, 1.5, -18.0), (0.0, 1.0, 0.0)),
+            ((0.0, 1.5, -18.0), (0.0, 1.0, 0.0)),      # same frame again: exact fit
+            ((0.3, 1.6, -17.5), (0.0, 1.0, 0.0)),      # a small move
+            ((0.0, 1.5, -18.0), (0.0, 30.0, -60.0)),   # away from the glass: few secondary rays or none
+            ((0.0, 1.5, -6.0), (0.0, 1.0, 0.0)),       # back to the glass, close: far more rays than hinted
+            ((0.0, 1.5, -6.0), (0.0, 1.0, 0.0))]
+    moving, _ = load_pair(pkg, root, "glass", (w, h))
+    for k, (frm, to) in enumerate(cams):
+        moving.set_camera(w, h, fov, frm, to, (0.0, 1.0, 0.0))
+        got, st = moving.render()
+        fresh, _ = load_pair(pkg, root, "glass", (w, h))
+        fresh.set_camera(w, h, fov, frm, to, (0.0, 1.0, 0.0))
+        want, st0 = fresh.render()
+        print("frame", k, "rays", st.rays, "generations", st.generations)
+        assert np.array_equal(got["rgb64"], want["rgb64"]) and np.array_equal(got["rgb8"], want["rgb8"])
+        assert np.array_equal(got["hit_leaf"], want["hit_leaf"])
+        assert (st.primary, st.shadow, st.reflect, st.refract, st.generations) == (
+            st0.primary, st0.shadow, st0.reflect, st0.refract, st0.generations)
+
+
 def test_parts_tile_the_image(pkg, root):
     gpu, _ = load_pair(pkg, root, "glass", (200, 120))
     whole, _ = gpu.render()

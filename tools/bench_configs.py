@@ -31,7 +31,7 @@ def run(pkg, name, path, size, frames, cameras=None, counters=False):
     info, foot = scene.info(), scene.footprint()
     w, h = info["width"], info["height"]
     frame = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
-    for k in range(2):
+    for k in range(8):  # first touches of freshly allocated ray queues, clocks
         scene.render_device(rgb8_ptr=frame.data_ptr())
     torch.cuda.synchronize()
     kernel_ms = render_ms = 0.0
@@ -61,7 +61,7 @@ def run(pkg, name, path, size, frames, cameras=None, counters=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--sweep-frames", type=int, default=60)
     ap.add_argument("--only", default="")
     ap.add_argument("--counters", action="store_true")
