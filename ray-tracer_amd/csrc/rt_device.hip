@@ -1253,6 +1253,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     }
   }
 
+  bool keep_record = false;
   if (MODE != 0) {
     // next generation: one atomic per wave that has something to append
     uint32_t child_reflect = REF_NONE, child_refract = REF_NONE;
@@ -1272,8 +1273,12 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
       next.dx[ti] = refract_ray.d.x; next.dy[ti] = refract_ray.d.y; next.dz[ti] = refract_ray.d.z;
       child_refract = ti;
     }
-    if (has_record) {
-      g.flags[rec] = flags;
+    // Camera rays write their pixel below; only those with children are looked at again
+    // (k_resolve_pixels), so the others leave nothing but their flags.
+    if (child_reflect != REF_NONE || child_refract != REF_NONE) flags |= 4u;
+    keep_record = has_record && (MODE == 2 || (flags & 4u));
+    if (has_record) g.flags[rec] = flags;
+    if (keep_record) {
       g.leaf[rec] = leaf;
       g.child_reflect[rec] = child_reflect;
       g.child_refract[rec] = child_refract;
@@ -1302,9 +1307,8 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     out_b = SQ.found ? ab : lb;
   }
   RT_STAMP(3);  // shadow traversal
-  if (MODE == 0) {
-    write_pixel(img, cam.hsize, px, py, i, active, out_r, out_g, out_b, leaf);
-  } else if (has_record) {
+  if (MODE != 2) write_pixel(img, cam.hsize, px, py, i, active, out_r, out_g, out_b, leaf);
+  if (MODE != 0 && keep_record) {
     g.cr[rec] = out_r; g.cg[rec] = out_g; g.cb[rec] = out_b;
   }
 
@@ -1323,19 +1327,12 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
   RT_STAMP(4);  // output
 }
 
-// shade_hit's final expression (src/world.rs:236-245), children first.
-__global__ void __launch_bounds__(BLOCK)
-    k_resolve(GenView g, uint32_t n, GenView next, const uint32_t* queue_counts, uint32_t segcap) {
-  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  bool active = i < n;
-  if (queue_counts) {  // spawned rays: records found through the segment counters
-    uint32_t rec;
-    active = queue_slot(queue_counts, segcap, i, rec) && active;
-    i = rec;
-  }
-  if (!active) return;
-  uint32_t flags = g.flags[i];
-  if (!(flags & 1u)) return;
+// shade_hit's final expression (src/world.rs:236-245) for record i, its children resolved already.
+// A record without children keeps its surface colour (returns false, nothing written).
+DEV bool resolve_record(const GenView& g, const GenView& next, uint32_t i, double* out_r = nullptr,
+                        double* out_g = nullptr, double* out_b = nullptr) {
+  const uint32_t flags = g.flags[i];
+  if (!(flags & 4u)) return false;
   uint32_t cr = g.child_reflect[i], cf = g.child_refract[i];
   double rr = 0.0, rg = 0.0, rb = 0.0, fr = 0.0, fg = 0.0, fb = 0.0;
   if (cr != REF_NONE) {
@@ -1346,31 +1343,58 @@ __global__ void __launch_bounds__(BLOCK)
     double k = g.transparency[i];
     fr = next.cr[cf] * k; fg = next.cg[cf] * k; fb = next.cb[cf] * k;
   }
-  double sr = g.cr[i], sg = g.cg[i], sb = g.cb[i];
+  double r = g.cr[i], gg = g.cg[i], b = g.cb[i];
   if (flags & 2u) {
     double R = g.reflectance[i];
-    g.cr[i] = sr + rr * R + fr * (1.0 - R);
-    g.cg[i] = sg + rg * R + fg * (1.0 - R);
-    g.cb[i] = sb + rb * R + fb * (1.0 - R);
+    r = r + rr * R + fr * (1.0 - R);
+    gg = gg + rg * R + fg * (1.0 - R);
+    b = b + rb * R + fb * (1.0 - R);
   } else {
-    g.cr[i] = sr + rr + fr;
-    g.cg[i] = sg + rg + fg;
-    g.cb[i] = sb + rb + fb;
+    r = r + rr + fr;
+    gg = gg + rg + fg;
+    b = b + rb + fb;
   }
+  if (out_r) {
+    *out_r = r; *out_g = gg; *out_b = b;
+  } else {
+    g.cr[i] = r; g.cg[i] = gg; g.cb[i] = b;
+  }
+  return true;
 }
 
+// Children first: generation g is resolved after generation g + 1.
 __global__ void __launch_bounds__(BLOCK)
-    k_output_image(GenView g, uint32_t n, CameraDev cam, const uint32_t* tiles, uint32_t tiles_x, ImageOut img) {
+    k_resolve(GenView g, uint32_t n, GenView next, const uint32_t* queue_counts, uint32_t segcap) {
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  uint32_t x = 0, y = 0;
-  const bool active = i < n && ray_pixel(tiles, tiles_x, cam, i, x, y);
-  double r = 0.0, gg = 0.0, b = 0.0;
-  int leaf = -1;
-  if (active) {
-    r = g.cr[i]; gg = g.cg[i]; b = g.cb[i];
-    leaf = g.leaf[i];
+  bool active = i < n;
+  if (queue_counts) {  // spawned rays: records found through the segment counters
+    uint32_t rec;
+    active = queue_slot(queue_counts, segcap, i, rec) && active;
+    i = rec;
   }
-  write_pixel(img, cam.hsize, x, y, i, active, r, gg, b, leaf);
+  if (!active) return;
+  resolve_record(g, next, i);
+}
+
+// The last step of a camera frame with secondary rays: the pixels whose primary ray had children get
+// their final colour (the kernel of generation 0 wrote every pixel with the surface colour alone).
+__global__ void __launch_bounds__(BLOCK)
+    k_resolve_pixels(GenView g, uint32_t n, GenView next, CameraDev cam, const uint32_t* tiles, uint32_t tiles_x,
+                     ImageOut img) {
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double r, gg, b;
+  if (!resolve_record(g, next, i, &r, &gg, &b)) return;
+  uint32_t x = 0, y = 0;
+  if (!ray_pixel(tiles, tiles_x, cam, i, x, y)) return;
+  const size_t p = (size_t)y * cam.hsize + x;
+  if (img.rgb64) {
+    img.rgb64[p * 3 + 0] = r; img.rgb64[p * 3 + 1] = gg; img.rgb64[p * 3 + 2] = b;
+  }
+  if (img.rgb8) {
+    uint8_t* dst = img.rgb8 + (img.compact ? (size_t)i : p) * 3;
+    dst[0] = quantise(r); dst[1] = quantise(gg); dst[2] = quantise(b);
+  }
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -2483,6 +2507,14 @@ void launch_resolve(rt_scene* s, const GenPlan& plan, int g) {
                      g > 0 ? s->d_counts + (g - 1) * QUEUE_SEGMENTS : (const uint32_t*)nullptr, plan.segcap[g]);
 }
 
+// Colours flow back from the last generation to the first; a camera frame ends in its pixels.
+void launch_resolves(rt_scene* s, const PipelineIn& in, const GenPlan& plan, int last) {
+  for (int g = last - 1; g >= (in.camera ? 1 : 0); g--) launch_resolve(s, plan, g);
+  if (in.camera && last > 0)
+    hipLaunchKernelGGL(k_resolve_pixels, dim3(blocks_for(in.n0)), dim3(BLOCK), 0, s->stream, s->gens[0].view, in.n0,
+                       s->gens[1].view, in.cam, in.tiles, in.tiles_x, in.img);
+}
+
 // The frame launched at once on twice the queue lengths of the frame before (scene->hint; unused room
 // costs waves that exit at once):
 // no host round trip between the generations; the kernels find their rays through the segment counters
@@ -2517,10 +2549,7 @@ int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_stats* st
     launch_generation(s, (g == 0 && in.camera) ? 1 : 2, false, a);
   }
   HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-  for (int g = last - 1; g >= 0; g--) launch_resolve(s, plan, g);
-  if (in.camera)
-    hipLaunchKernelGGL(k_output_image, dim3(blocks_for(in.n0)), dim3(BLOCK), 0, s->stream, s->gens[0].view, in.n0,
-                       in.cam, in.tiles, in.tiles_x, in.img);
+  launch_resolves(s, in, plan, last);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -2630,10 +2659,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     }
 #endif
   }
-  for (int g = last - 1; g >= 0; g--) launch_resolve(s, plan, g);
-  if (in.camera && !direct)
-    hipLaunchKernelGGL(k_output_image, dim3(blocks_for(in.n0)), dim3(BLOCK), 0, s->stream, s->gens[0].view, in.n0,
-                       in.cam, in.tiles, in.tiles_x, in.img);
+  launch_resolves(s, in, plan, last);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                          s->stream));
