@@ -275,6 +275,22 @@ int rt_intersect_hit(rt_scene* scene, uint64_t n, const double* rays6, double* t
 /* `World::is_shadowed` for n points (n x 3 doubles) -> n bytes.  Host buffers. */
 int rt_is_shadowed(rt_scene* scene, uint64_t n, const double* points3, uint8_t* shadowed);
 
+/* `Canvas::save` (src/canvas.rs:47-94) on the device: the rgb8 frame at rgb8_dev (device memory of
+ * `device`, width * height * 3 bytes, row-major, finished - call rt_scene_wait first if it was
+ * rendered with RT_FLAG_ASYNC) becomes the text of the reference's PPM file in out_dev (device memory,
+ * capacity >= rt_ppm_max_bytes(width, height)): header, numbers, the reference's 70-column line
+ * breaks, final newline, byte for byte.  *length receives the size of the file.  Blocking; uses a
+ * temporary workspace of about 2.3 bytes per pixel.  The file then crosses PCIe once (rt_download
+ * or hipMemcpy) instead of being formatted from a host copy of the frame. */
+int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
+                  uint64_t capacity, uint64_t* length);
+/* The same for a frame and a file in host memory (staged through `device`; page-locked buffers from
+ * rt_host_alloc move fastest).  When capacity is too small, *length still receives the size needed. */
+int rt_ppm_encode_host(int device, const uint8_t* rgb8_host, uint64_t width, uint64_t height, char* out_host,
+                       uint64_t capacity, uint64_t* length);
+/* Upper bound of the file size: 12 bytes per pixel, the header, the final newline. */
+uint64_t rt_ppm_max_bytes(uint64_t width, uint64_t height);
+
 /* Diagnostic, host only (no GPU needed): checks the direction index that finds the cones whose
  * parallel-ray branch (src/shape.rs:1089-1103) a ray direction triggers.  Builds the index over
  * n_bands random cones and looks up n_dirs random directions; returns the number of cones the

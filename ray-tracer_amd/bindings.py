@@ -98,6 +98,10 @@ def libraries():
     amd.rt_color_at.argtypes = [vp, u64, vp, i32, u32, vp, vp, C.POINTER(RtStats)]
     amd.rt_intersect_hit.argtypes = [vp, u64, vp, vp, vp]
     amd.rt_is_shadowed.argtypes = [vp, u64, vp, vp]
+    amd.rt_ppm_encode.argtypes = [i32, vp, u64, u64, vp, u64, C.POINTER(u64)]
+    amd.rt_ppm_encode_host.argtypes = [i32, vp, u64, u64, vp, u64, C.POINTER(u64)]
+    amd.rt_ppm_max_bytes.argtypes = [u64, u64]
+    amd.rt_ppm_max_bytes.restype = u64
     host.rth_last_error.restype = C.c_char_p
     host.rth_scene_from_json.argtypes = [C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]
     host.rth_scene_free.argtypes = [vp]
@@ -135,6 +139,37 @@ def ppm_encode(rgb8):
     buf = C.create_string_buffer(size)
     host.rth_ppm_encode(w, h, _ptr(img), buf, size)
     return buf.raw
+
+
+def ppm_max_bytes(width, height):
+    """Size of the device buffer ppm_encode_device needs for a width x height frame."""
+    amd, _ = libraries()
+    return int(amd.rt_ppm_max_bytes(width, height))
+
+
+def ppm_encode_device(rgb8_ptr, width, height, out_ptr, capacity, device=0):
+    """Canvas::save's text (src/canvas.rs:47-94) written on the GPU: rgb8_ptr and out_ptr are device
+    addresses.  Returns the length of the file in out_ptr."""
+    amd, _ = libraries()
+    n = C.c_uint64()
+    rc = amd.rt_ppm_encode(device, rgb8_ptr, width, height, out_ptr, capacity, C.byref(n))
+    if rc != 0:
+        raise RtError(rc, amd.rt_last_error().decode())
+    return int(n.value)
+
+
+def ppm_encode_via_device(rgb8, device=0):
+    """Canvas::save's text for an (H, W, 3) uint8 host image, formatted on the GPU."""
+    amd, _ = libraries()
+    img = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _c = img.shape
+    cap = int(amd.rt_ppm_max_bytes(w, h))
+    buf = np.empty(cap, np.uint8)
+    n = C.c_uint64()
+    rc = amd.rt_ppm_encode_host(device, _ptr(img), w, h, _ptr(buf), cap, C.byref(n))
+    if rc != 0:
+        raise RtError(rc, amd.rt_last_error().decode())
+    return buf[: n.value].tobytes()
 
 
 class Scene:

@@ -39,6 +39,7 @@
 #include "../../include/rt_amd.h"
 #include "band_grid.h"
 #include "bvh_build.h"
+#include "rt_error.h"
 #include "rt_types.h"
 
 using namespace rt;
@@ -51,6 +52,7 @@ static int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+int rt_fail_message(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 #define HIP_TRY(expr)                                                                       \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \

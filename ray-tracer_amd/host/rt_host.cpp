@@ -10,6 +10,8 @@
 #include <fstream>
 #include <limits>
 #include <sstream>
+#include <chrono>
+#include <memory>
 #include <thread>
 
 namespace rthost {
@@ -947,10 +949,20 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
   // `jobs` counts worker threads in the reference; here one worker drives one GPU, so a request for
   // more workers than GPUs uses every GPU there is
   if ((size_t)have < jobs) jobs = (size_t)have;
+  // RT_AMD_TIMINGS=1: where the wall time of one call goes, on stderr
+  const bool timings = getenv("RT_AMD_TIMINGS") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto lap = [&](const char* what, std::chrono::steady_clock::time_point& t) {
+    auto t1 = now();
+    if (timings) fprintf(stderr, "[rt_host] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t).count());
+    t = t1;
+  };
+  auto t = now();
   FlatWorld flat = flatten(world);
   rt_scene_desc desc = flat.desc();
   rt_camera cam = camera.describe();
   size_t np = camera.hsize * camera.vsize;
+  lap("flatten", t);
   // One frame for all GPUs: part k is the bands of 32 pixel rows k, k + jobs, ... and every worker
   // copies exactly its bands into the frame, so the pieces need no merging afterwards.
   struct Frame {
@@ -963,6 +975,7 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
   } frame;
   frame.p = (uint8_t*)rt_host_alloc(np * 3);
   frame.pinned = frame.p != nullptr;
+  lap("device start, frame memory", t);
   if (!frame.p) frame.p = (uint8_t*)malloc(std::max<size_t>(np * 3, 1));
   if (!frame.p) throw std::bad_alloc();
   std::vector<std::string> errors(jobs);
@@ -979,10 +992,22 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
   for (auto& t : threads) t.join();
   for (const std::string& e : errors)
     if (!e.empty()) throw std::runtime_error(e);
-  std::string ppm = ppm_encode(camera.hsize, camera.vsize, frame.p);
+  lap("scene upload, BVH, render", t);
+  // Canvas::save (src/canvas.rs:47-94): the text is formatted on the first GPU (the frame goes up,
+  // the file comes down), about ten times faster than this host's one-core writer at 4K
+  // (pageable memory for the text: page-locking 12 bytes per pixel for one copy costs more than it saves)
+  const uint64_t cap = rt_ppm_max_bytes(camera.hsize, camera.vsize);
+  std::unique_ptr<char, void (*)(void*)> text((char*)malloc(cap), free);
+  if (!text) throw std::bad_alloc();
+  uint64_t length = 0;
+  if (rt_ppm_encode_host(0, frame.p, camera.hsize, camera.vsize, text.get(), cap, &length) != RT_OK)
+    throw std::runtime_error(rt_last_error());
+  lap("PPM text (device)", t);
   std::ofstream of(out_path, std::ios::binary);
   if (!of) throw Panic("could not create output file " + out_path);
-  of.write(ppm.data(), (std::streamsize)ppm.size());
+  of.write(text.get(), (std::streamsize)length);
+  of.close();
+  lap("file write", t);
   printf("...done.\n\n");
   printf("Saved render to \"%s\".\n", out_path.c_str());
 }
