@@ -9,6 +9,7 @@ a thin ctypes binding; there is no CPU fallback: a missing library raises.
 """
 from . import bindings, tiles  # noqa: F401
 from .bindings import (  # noqa: F401
+    Canvas,
     RtCamera,
     RtStats,
     RtError,

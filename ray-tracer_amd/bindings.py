@@ -112,6 +112,15 @@ def libraries():
     host.rth_scene_set_canvas.argtypes = [vp, u64, u64]
     host.rth_scene_set_camera.argtypes = [vp, u64, u64, C.c_double, dp, dp, dp]
     host.rth_parallel_render.argtypes = [vp, u64, C.c_char_p]
+    host.rth_canvas_new.argtypes = [u64, u64, C.POINTER(vp)]
+    host.rth_render_canvas.argtypes = [vp, u64, C.POINTER(vp)]
+    host.rth_canvas_free.argtypes = [vp]
+    host.rth_canvas_size.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    host.rth_canvas_write_pixel.argtypes = [vp, u64, u64, dp]
+    host.rth_canvas_read_pixel.argtypes = [vp, u64, u64, dp]
+    host.rth_canvas_pixels.argtypes = [vp]
+    host.rth_canvas_pixels.restype = dp
+    host.rth_canvas_save.argtypes = [vp, C.c_char_p]
     host.rth_ppm_encode.argtypes = [u64, u64, vp, vp, u64]
     host.rth_ppm_encode.restype = u64
     _libs = (amd, host)
@@ -170,6 +179,47 @@ def ppm_encode_via_device(rgb8, device=0):
     if rc != 0:
         raise RtError(rc, amd.rt_last_error().decode())
     return buf[: n.value].tobytes()
+
+
+class Canvas:
+    """Canvas (src/canvas.rs:22-140): f64 colours, row-major; read_pixel returns None outside the image."""
+
+    def __init__(self, width=0, height=0, _handle=None):
+        _, self._host = libraries()
+        if _handle is None:
+            h = C.c_void_p()
+            rc = self._host.rth_canvas_new(width, height, C.byref(h))
+            if rc != 0:
+                raise RtError(rc, self._host.rth_last_error().decode())
+            _handle = h
+        self._c = _handle
+        w, hh = C.c_uint64(), C.c_uint64()
+        self._host.rth_canvas_size(self._c, C.byref(w), C.byref(hh))
+        self.width, self.height = int(w.value), int(hh.value)
+
+    def __del__(self):
+        if getattr(self, "_c", None):
+            self._host.rth_canvas_free(self._c)
+            self._c = None
+
+    def write_pixel(self, x, y, rgb):
+        self._host.rth_canvas_write_pixel(self._c, x, y, (C.c_double * 3)(*rgb))
+
+    def read_pixel(self, x, y):
+        out = (C.c_double * 3)()
+        return tuple(out) if self._host.rth_canvas_read_pixel(self._c, x, y, out) else None
+
+    def pixels(self):
+        """(H, W, 3) float64 copy of the canvas."""
+        if self.width * self.height == 0:
+            return np.zeros((self.height, self.width, 3))
+        p = self._host.rth_canvas_pixels(self._c)
+        return np.ctypeslib.as_array(p, shape=(self.height, self.width, 3)).copy()
+
+    def save(self, path):
+        rc = self._host.rth_canvas_save(self._c, str(path).encode())
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
 
 
 class Scene:
@@ -321,6 +371,14 @@ class Scene:
         rc = self._host.rth_parallel_render(self._h, jobs, str(out_path).encode())
         if rc != 0:
             raise RtError(rc, self._host.rth_last_error().decode())
+
+    def render_canvas(self, jobs=1):
+        """The canvas parallel_render holds before it saves (src/parallel.rs:185-200)."""
+        h = C.c_void_p()
+        rc = self._host.rth_render_canvas(self._h, jobs, C.byref(h))
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
+        return Canvas(_handle=h)
 
     # ---- batch forms of the reference's per-ray API
     def ray_for_pixel(self, xy):

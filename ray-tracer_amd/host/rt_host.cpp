@@ -937,6 +937,80 @@ std::string ppm_encode(size_t width, size_t height, const uint8_t* rgb8) {
 }
 
 // ===========================================================================
+// Canvas (src/canvas.rs:22-140)
+// ===========================================================================
+Canvas::Canvas(size_t w, size_t h) : width(w), height(h), pixels(w * h) {}
+
+void Canvas::write_pixel(size_t x, size_t y, const Color& pixel) {
+  if (x >= width || y >= height) return;
+  pixels[y * width + x] = pixel;
+}
+
+std::optional<Color> Canvas::read_pixel(size_t x, size_t y) const {
+  if (x >= width || y >= height) return std::nullopt;
+  return pixels[y * width + x];
+}
+
+std::vector<uint8_t> Canvas::quantised() const {
+  auto q = [](double c) -> uint8_t {
+    double v = c * 255.0;  // f64::clamp keeps NaN, `as usize` turns it into 0
+    if (v < 0.0) v = 0.0;
+    else if (v > 255.0) v = 255.0;
+    v = std::ceil(v);
+    return v == v ? (uint8_t)v : (uint8_t)0;
+  };
+  std::vector<uint8_t> out(pixels.size() * 3);
+  for (size_t p = 0; p < pixels.size(); p++) {
+    out[p * 3 + 0] = q(pixels[p].r);
+    out[p * 3 + 1] = q(pixels[p].g);
+    out[p * 3 + 2] = q(pixels[p].b);
+  }
+  return out;
+}
+
+void Canvas::save(const std::string& path) const {
+  std::vector<uint8_t> rgb8 = quantised();
+  const uint64_t cap = rt_ppm_max_bytes(width, height);
+  std::unique_ptr<char, void (*)(void*)> text((char*)malloc(cap), free);
+  if (!text) throw std::bad_alloc();
+  uint64_t length = 0;
+  if (rt_ppm_encode_host(0, rgb8.data(), width, height, text.get(), cap, &length) != RT_OK)
+    throw std::runtime_error(rt_last_error());
+  std::ofstream of(path, std::ios::binary);
+  if (!of) throw Panic("could not create output file " + path);
+  of.write(text.get(), (std::streamsize)length);
+}
+
+Canvas render_canvas(const World& world, const Camera& camera, size_t jobs) {
+  if (jobs == 0) throw Panic("assertion failed: size > 0");  // src/parallel.rs:94
+  int have = rt_device_count();
+  if (have < 0) throw std::runtime_error(rt_last_error());
+  if (have == 0) throw std::runtime_error("no GPU visible");
+  if ((size_t)have < jobs) jobs = (size_t)have;
+  FlatWorld flat = flatten(world);
+  rt_scene_desc desc = flat.desc();
+  rt_camera cam = camera.describe();
+  Canvas canvas(camera.hsize, camera.vsize);
+  static_assert(sizeof(Color) == 3 * sizeof(double), "Color is three packed doubles");
+  double* rgb64 = canvas.pixels.empty() ? nullptr : &canvas.pixels[0].r;
+  std::vector<std::string> errors(jobs);
+  auto worker = [&](size_t k) {  // every GPU writes its bands of 32 rows straight into the canvas
+    rt_scene* sc = nullptr;
+    if (rt_scene_create(&desc, (int)k, &sc) != RT_OK ||
+        rt_render_host(sc, &cam, (int)k, (int)jobs, RT_FLAG_BANDS, nullptr, rgb64, nullptr, nullptr) != RT_OK)
+      errors[k] = rt_last_error();
+    rt_scene_destroy(sc);
+  };
+  std::vector<std::thread> threads;
+  for (size_t k = 1; k < jobs; k++) threads.emplace_back(worker, k);
+  worker(0);
+  for (auto& t : threads) t.join();
+  for (const std::string& e : errors)
+    if (!e.empty()) throw std::runtime_error(e);
+  return canvas;
+}
+
+// ===========================================================================
 // parallel_render (src/parallel.rs:183-204): image tiles over `jobs` GPUs
 // ===========================================================================
 void parallel_render(const World& world, const Camera& camera, size_t jobs, const std::string& out_path) {

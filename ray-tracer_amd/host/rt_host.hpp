@@ -105,6 +105,26 @@ FlatWorld flatten(const World& w);
 // Canvas::save (src/canvas.rs:47-94) from already quantised bytes.
 std::string ppm_encode(size_t width, size_t height, const uint8_t* rgb8);
 
+struct Color {  // src/color.rs:10-19
+  double r = 0, g = 0, b = 0;
+};
+
+// Canvas (src/canvas.rs:22-140): the frame as f64 colours, row-major.
+class Canvas {
+ public:
+  size_t width = 0, height = 0;
+  std::vector<Color> pixels;
+  Canvas(size_t width, size_t height);                          // black (src/canvas.rs:35-41)
+  void write_pixel(size_t x, size_t y, const Color& pixel);     // out of bounds: ignored (src/canvas.rs:114-121)
+  std::optional<Color> read_pixel(size_t x, size_t y) const;    // out of bounds: nothing (src/canvas.rs:132-139)
+  std::vector<uint8_t> quantised() const;                       // ceil(clamp(c * 255, 0, 255)) (src/canvas.rs:60-62)
+  void save(const std::string& path) const;                     // src/canvas.rs:47-94, the text formatted on GPU 0
+};
+
+// The canvas parallel_render holds when its workers are done (src/parallel.rs:185-200), rendered by
+// `jobs` GPUs.
+Canvas render_canvas(const World& world, const Camera& camera, size_t jobs);
+
 // parallel_render (src/parallel.rs:183-204): `jobs` is the number of GPUs.
 void parallel_render(const World& world, const Camera& camera, size_t jobs, const std::string& out_path);
 

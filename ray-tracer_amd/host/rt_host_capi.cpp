@@ -108,6 +108,57 @@ int rth_parallel_render(rth_scene* h, uint64_t jobs, const char* out_path) {
   });
 }
 
+// ---- Canvas (src/canvas.rs:22-140)
+struct rth_canvas {
+  Canvas canvas;
+};
+
+int rth_canvas_new(uint64_t w, uint64_t hh, rth_canvas** out) {
+  *out = nullptr;
+  return guarded([&]() -> int {
+    *out = new rth_canvas{Canvas(w, hh)};
+    return RT_OK;
+  });
+}
+
+// The frame parallel_render would save, as a canvas.
+int rth_render_canvas(rth_scene* h, uint64_t jobs, rth_canvas** out) {
+  *out = nullptr;
+  return guarded([&]() -> int {
+    *out = new rth_canvas{render_canvas(h->scene.world, h->scene.camera, jobs)};
+    return RT_OK;
+  });
+}
+
+void rth_canvas_free(rth_canvas* c) { delete c; }
+
+void rth_canvas_size(const rth_canvas* c, uint64_t* w, uint64_t* hh) {
+  *w = c->canvas.width;
+  *hh = c->canvas.height;
+}
+
+void rth_canvas_write_pixel(rth_canvas* c, uint64_t x, uint64_t y, const double* rgb) {
+  c->canvas.write_pixel(x, y, Color{rgb[0], rgb[1], rgb[2]});
+}
+
+// 1 and the colour, or 0 for a pixel outside the canvas (the reference returns None).
+int rth_canvas_read_pixel(const rth_canvas* c, uint64_t x, uint64_t y, double* rgb) {
+  std::optional<Color> p = c->canvas.read_pixel(x, y);
+  if (!p) return 0;
+  rgb[0] = p->r; rgb[1] = p->g; rgb[2] = p->b;
+  return 1;
+}
+
+// All pixels, row-major, three doubles each.
+const double* rth_canvas_pixels(const rth_canvas* c) { return c->canvas.pixels.empty() ? nullptr : &c->canvas.pixels[0].r; }
+
+int rth_canvas_save(const rth_canvas* c, const char* path) {
+  return guarded([&]() -> int {
+    c->canvas.save(path);
+    return RT_OK;
+  });
+}
+
 uint64_t rth_ppm_encode(uint64_t w, uint64_t hh, const uint8_t* rgb8, char* buf, uint64_t cap) {
   std::string s = ppm_encode(w, hh, rgb8);
   if (buf && cap) memcpy(buf, s.data(), s.size() < cap ? s.size() : cap);

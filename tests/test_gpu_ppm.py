@@ -78,3 +78,38 @@ def test_device_ppm_refuses_a_small_buffer(pkg):
     out = torch.empty((16,), dtype=torch.uint8, device="cuda:0")
     with pytest.raises(pkg.bindings.RtError):
         pkg.bindings.ppm_encode_device(frame.data_ptr(), 4, 4, out.data_ptr(), 16)
+
+
+def test_canvas_read_write_and_save(pkg, root, tmp_path):
+    """The reference's Canvas doctest (src/canvas.rs:104-113) and its out-of-bounds rules, then a
+    rendered canvas: read_pixel returns the f64 colours of the render, save writes the reference file."""
+    import os
+    c = pkg.Canvas(8, 8)
+    assert c.read_pixel(4, 2) == (0.0, 0.0, 0.0)
+    c.write_pixel(4, 2, (1.0, 0.0, 1.0))
+    assert c.read_pixel(4, 2) == (1.0, 0.0, 1.0)
+    c.write_pixel(8, 2, (1.0, 1.0, 1.0))  # silently ignored (src/canvas.rs:115-118)
+    c.write_pixel(2, 8, (1.0, 1.0, 1.0))
+    assert c.read_pixel(8, 2) is None and c.read_pixel(0, 8) is None
+    assert c.pixels().sum() == 2.0
+
+    path = os.path.join(root, "scenes", "glass.json")
+    gpu = pkg.Scene.from_file(path, base_dir=root, device=0)
+    gpu.set_canvas(97, 61)
+    cpu = orc.OracleScene.from_file(path, base_dir=root)
+    cpu.set_canvas(97, 61)
+    canvas = gpu.render_canvas(jobs=1)
+    assert (canvas.width, canvas.height) == (97, 61)
+    out, _ = gpu.render()
+    assert np.array_equal(canvas.pixels(), out["rgb64"])
+    assert canvas.read_pixel(96, 60) == tuple(out["rgb64"][60, 96])
+    assert canvas.read_pixel(97, 0) is None
+    want = cpu.render(jobs=8)
+    assert np.abs(canvas.pixels() - want["rgb64"]).max() <= 1e-9
+    file = tmp_path / "canvas.ppm"
+    canvas.save(file)
+    assert file.read_bytes() == orc.ppm_encode(canvas.pixels())
+    canvas.write_pixel(0, 0, (float("nan"), -1.0, 2.0))  # NaN -> 0, clamp (src/canvas.rs:60-62)
+    canvas.save(file)
+    assert file.read_bytes() == orc.ppm_encode(canvas.pixels())
+    assert file.read_bytes().split(b"\n")[3].startswith(b"0 0 255 ")
