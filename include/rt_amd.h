@@ -298,6 +298,14 @@ uint64_t rt_ppm_max_bytes(uint64_t width, uint64_t height);
  * No counterpart in the reference, which scans every shape for every ray. */
 int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int* grid_n, uint64_t* entries);
 
+/* Diagnostic, host only: builds the acceleration structure over n_items random boxes (70 % triangle
+ * slots, 30 % quadric slots) with `threads` build threads (0 = default) and returns a hash of every
+ * byte the build produced (nodes, primitive orders, bounds, stack depth), the node count and the time
+ * taken.  The hash must not depend on the thread count.  No counterpart in the reference, whose groups
+ * are scanned linearly (src/shape.rs:1213-1219). */
+int rt_selftest_bvh_build(int n_items, uint64_t seed, int threads, uint64_t* hash, uint64_t* n_nodes,
+                          double* seconds);
+
 #ifdef __cplusplus
 }
 #endif

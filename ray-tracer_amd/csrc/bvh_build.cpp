@@ -5,9 +5,13 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <future>
 #include <limits>
+#include <thread>
 
 namespace rt {
 namespace {
@@ -73,7 +77,33 @@ uint32_t BvhBuilder::make_leaf(BuildItem* items, size_t n) {
   return make_run(k, first, (uint32_t)n);
 }
 
-uint32_t BvhBuilder::build_range(BuildItem* items, size_t n, int depth, double lo[3], double hi[3]) {
+// Appends a finished sub-builder's binary nodes and primitive orders to this builder and returns `ref`
+// (a reference inside the sub-builder) as a reference inside this one.
+uint32_t BvhBuilder::splice(const BvhBuilder& sub, uint32_t ref) {
+  const uint32_t bin_off = (uint32_t)bin_.size(), tri_off = (uint32_t)tri_order.size(),
+                 quad_off = (uint32_t)quad_order.size();
+  auto moved = [&](uint32_t r) -> uint32_t {
+    if (r == REF_NONE) return r;
+    switch (r >> 30) {
+      case KIND_INNER: return r + bin_off;
+      case KIND_TRI: return r + tri_off;    // the run's first slot sits in the low bits
+      case KIND_QUAD: return r + quad_off;
+      default: return r;                    // gates are numbered by the caller
+    }
+  };
+  for (BinNode nd : sub.bin_) {
+    nd.c[0] = moved(nd.c[0]);
+    nd.c[1] = moved(nd.c[1]);
+    bin_.push_back(nd);
+  }
+  tri_order.insert(tri_order.end(), sub.tri_order.begin(), sub.tri_order.end());
+  quad_order.insert(quad_order.end(), sub.quad_order.begin(), sub.quad_order.end());
+  return moved(ref);
+}
+
+constexpr size_t PARALLEL_MIN_ITEMS = 16384;  // below this a range is not worth a thread
+
+uint32_t BvhBuilder::build_range(BuildItem* items, size_t n, int depth, double lo[3], double hi[3], int threads) {
   Box box, cbox;
   for (size_t i = 0; i < n; i++) {
     box.grow(items[i].lo, items[i].hi);
@@ -164,8 +194,22 @@ uint32_t BvhBuilder::build_range(BuildItem* items, size_t n, int depth, double l
   uint32_t idx = (uint32_t)bin_.size();
   bin_.emplace_back();
   double l0[3], h0[3], l1[3], h1[3];
-  uint32_t c0 = build_range(items, mid, depth + 1, l0, h0);
-  uint32_t c1 = build_range(items + mid, n - mid, depth + 1, l1, h1);
+  uint32_t c0, c1;
+  if (threads > 1 && n >= PARALLEL_MIN_ITEMS) {
+    BvhBuilder left, right;
+    const int left_threads = std::max(1, (int)((double)threads * (double)mid / (double)n + 0.5));
+    const int right_threads = std::max(1, threads - left_threads);
+    auto other = std::async(std::launch::async, [&] {
+      return left.build_range(items, mid, depth + 1, l0, h0, left_threads);
+    });
+    uint32_t r1 = right.build_range(items + mid, n - mid, depth + 1, l1, h1, right_threads);
+    uint32_t r0 = other.get();
+    c0 = splice(left, r0);  // left first: the order of a single-threaded build
+    c1 = splice(right, r1);
+  } else {
+    c0 = build_range(items, mid, depth + 1, l0, h0, 1);
+    c1 = build_range(items + mid, n - mid, depth + 1, l1, h1, 1);
+  }
   BinNode& nd = bin_[idx];
   for (int a = 0; a < 3; a++) {
     nd.lo[0][a] = l0[a]; nd.hi[0][a] = h0[a];
@@ -275,8 +319,21 @@ uint32_t BvhBuilder::build(std::vector<BuildItem>& items, double lo[3], double h
     return REF_NONE;
   }
   bin_.clear();
-  uint32_t root = build_range(items.data(), items.size(), 1, lo, hi);
-  return collapse(root, &stack_need);
+  static const int default_threads = [] {
+    int t = env_int("RT_AMD_BUILD_THREADS", 0);
+    if (t <= 0) t = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return t;
+  }();
+  static const bool timing = getenv("RT_AMD_BUILD_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  uint32_t root = build_range(items.data(), items.size(), 1, lo, hi, threads > 0 ? threads : default_threads);
+  auto t1 = std::chrono::steady_clock::now();
+  uint32_t out = collapse(root, &stack_need);
+  if (timing && items.size() > 1000)
+    fprintf(stderr, "[rt_amd] build of %zu items: split %.1f ms, collapse %.1f ms\n", items.size(),
+            std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+  return out;
 }
 
 }  // namespace rt

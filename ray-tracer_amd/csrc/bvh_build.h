@@ -21,6 +21,7 @@ struct BvhBuilder {
   std::vector<BvhNode> nodes;
   std::vector<uint32_t> tri_order;   // source triangle index of every emitted TriIsect slot
   std::vector<uint32_t> quad_order;  // same for QuadPrim slots
+  int threads = 0;                   // build threads; 0: RT_AMD_BUILD_THREADS or the host's cores, at most 16
   int stack_need = 0;                // traversal stack entries the last build()'s subtree can need
   std::vector<int> gate_need;        // the same for the subtree behind each gate (indexed by gate)
   // What a ray that may skip the exact gate test walks instead of gate g: the subtree behind it (with
@@ -38,7 +39,10 @@ struct BvhBuilder {
 
  private:
   std::vector<BinNode> bin_;
-  uint32_t build_range(BuildItem* items, size_t n, int depth, double lo[3], double hi[3]);
+  // threads: how many threads this subtree may use; large ranges hand their two halves to builders of
+  // their own and splice the results in the order a single thread would have produced them
+  uint32_t build_range(BuildItem* items, size_t n, int depth, double lo[3], double hi[3], int threads);
+  uint32_t splice(const BvhBuilder& sub, uint32_t ref);
   uint32_t make_leaf(BuildItem* items, size_t n);
   uint32_t collapse(uint32_t bin_ref, int* need);
 };

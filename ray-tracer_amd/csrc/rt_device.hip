@@ -2185,6 +2185,49 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
 // directions (half of them placed inside a band); returns how many (direction, band) pairs that pass
 // the band pre-filter are missing from the direction's grid cell (0 when the index is conservative),
 // or a negative rt_status.  *grid_n receives the grid resolution, *entries its size.
+extern "C" int rt_selftest_bvh_build(int n_items, uint64_t seed, int threads, uint64_t* hash, uint64_t* n_nodes,
+                                     double* seconds) {
+  if (n_items < 0 || threads < 0 || !hash) return fail(RT_ERR_INVALID, "rt_selftest_bvh_build: bad argument");
+  uint64_t state = seed;
+  auto uniform = [&state]() {  // splitmix64
+    uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (double)((z ^ (z >> 31)) >> 11) / 9007199254740992.0;
+  };
+  std::vector<BuildItem> items((size_t)n_items);
+  for (int i = 0; i < n_items; i++) {
+    BuildItem& it = items[i];
+    for (int a = 0; a < 3; a++) {
+      double c = uniform() * 100.0, e = uniform() * 0.5;
+      it.lo[a] = c - e;
+      it.hi[a] = c + e;
+    }
+    it.kind = uniform() < 0.7 ? KIND_TRI : KIND_QUAD;
+    it.index = (uint32_t)i;
+  }
+  BvhBuilder b;
+  b.threads = threads;
+  double lo[3], hi[3];
+  auto t0 = std::chrono::steady_clock::now();
+  uint32_t root = b.build(items, lo, hi);
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  uint64_t h = 0xCBF29CE484222325ull ^ root;  // FNV-1a over everything the build produced
+  auto mix = [&h](const void* p, size_t n) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) h = (h ^ c[i]) * 0x100000001B3ull;
+  };
+  if (!b.nodes.empty()) mix(b.nodes.data(), b.nodes.size() * sizeof(BvhNode));
+  if (!b.tri_order.empty()) mix(b.tri_order.data(), b.tri_order.size() * sizeof(uint32_t));
+  if (!b.quad_order.empty()) mix(b.quad_order.data(), b.quad_order.size() * sizeof(uint32_t));
+  mix(lo, sizeof lo);
+  mix(hi, sizeof hi);
+  mix(&b.stack_need, sizeof b.stack_need);
+  *hash = h;
+  if (n_nodes) *n_nodes = b.nodes.size();
+  return RT_OK;
+}
+
 extern "C" int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int* grid_n, uint64_t* entries) {
   if (n_bands < 0 || n_dirs < 0) return fail(RT_ERR_INVALID, "negative count");
   uint64_t state = seed;

@@ -122,3 +122,23 @@ def test_cone_band_direction_index_is_conservative(pkg, n_bands, n_dirs):
         assert n.value == 0  # short lists are scanned, not indexed
     else:
         assert n.value >= 32 and entries.value > 0
+
+
+@pytest.mark.parametrize("n_items", [0, 1, 5000, 100000])
+def test_bvh_build_does_not_depend_on_the_thread_count(pkg, n_items):
+    """Large ranges are built by several threads and spliced together in the order one thread would
+    have produced: the structure (every node, the primitive orders, the stack depth) must come out
+    byte for byte the same, so image parity never depends on the machine's core count."""
+    amd, _ = pkg.libraries()
+    fn = amd.rt_selftest_bvh_build
+    fn.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64),
+                   ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
+    results = {}
+    for threads in (1, 2, 5, 8):
+        h, nodes, sec = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+        assert fn(n_items, 0xB0B + n_items, threads, ctypes.byref(h), ctypes.byref(nodes), ctypes.byref(sec)) == 0
+        results[threads] = (h.value, nodes.value)
+        print("items", n_items, "threads", threads, "nodes", nodes.value, "seconds %.4f" % sec.value)
+    assert len(set(results.values())) == 1
+    if n_items >= 5000:
+        assert results[1][1] > n_items // 16
