@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Canvas::save three ways on a rendered frame: the host writer (one core), rt_ppm_encode on a frame
 that is already in HBM (text left in HBM), and rt_ppm_encode_host (frame up, text down)."""
+import ctypes
 import json
 import os
 import sys
@@ -34,8 +35,11 @@ def main():
             n = b.ppm_encode_device(frame.data_ptr(), w, h, out.data_ptr(), cap)
         dev_ms = (time.perf_counter() - t0) / reps * 1e3
         host_frame = frame.cpu().numpy()
-        t0 = time.perf_counter()
         text = b.ppm_encode(host_frame)
+        _, host = b.libraries()
+        buf = ctypes.create_string_buffer(cap)
+        t0 = time.perf_counter()  # one pass of the host writer (the binding above runs it twice: size, then text)
+        host.rth_ppm_encode(w, h, host_frame.ctypes.data_as(ctypes.c_void_p), buf, cap)
         host_ms = (time.perf_counter() - t0) * 1e3
         b.ppm_encode_via_device(host_frame)
         t0 = time.perf_counter()
