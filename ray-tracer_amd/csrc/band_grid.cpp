@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cmath>
 #include <thread>
 
@@ -62,7 +63,8 @@ BandGrid build_band_grid(const std::vector<ConeBand>& bands, size_t max_items) {
   const size_t nb = bands.size();
   if (nb <= 32) return grid;  // a short list is cheaper to scan than to index
   int n = 32;
-  while (n < 2048 && n < 1.7 * (double)nb) n *= 2;
+  static const int n_max = getenv("RT_AMD_BAND_GRID_MAX") ? atoi(getenv("RT_AMD_BAND_GRID_MAX")) : 2048;  // experiment knob
+  while (n < n_max && n < 1.7 * (double)nb) n *= 2;
   const unsigned workers = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 
   for (;; n /= 2) {

@@ -371,6 +371,7 @@ struct LdsStack {
   static constexpr bool WITH_CSG = CSG;  // the kernels built for scenes with CSG operators carry eval_csg
   static constexpr bool UNIFORM_NODES = UNIFORM;  // ... and those for large hierarchies the scalar node path
   static constexpr int THREADS = BLOCK;
+  static constexpr int ENTRIES = STACK;
   uint32_t* base;
   uint32_t* csg;  // this lane's column of the CSG hit list (dynamic LDS), or null when the scene has no CSG
   int sp;
@@ -402,6 +403,7 @@ struct LdsStack {
   static constexpr bool WITH_CSG = CSG;
   static constexpr bool UNIFORM_NODES = UNIFORM;
   static constexpr int THREADS = BLOCK;
+  static constexpr int ENTRIES = STACK;
   uint32_t slot[STACK];
   uint32_t* csg;
   int sp;
@@ -660,8 +662,43 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       iu = iu < 0 ? 0 : (iu >= n ? n - 1 : iu);
       iv = iv < 0 ? 0 : (iv >= n ? n - 1 : iv);
       const uint32_t cell = ((uint32_t)m * n + iv) * n + iu;
+      // A cell lists every cone whose band crosses it (16 on average with 25 000 cones); the direction
+      // lies inside about one band in sixty.  Testing a cone the moment one lane finds it would run
+      // the intersection code for the whole wave about as often as there are list entries (some lane
+      // finds one at almost every step), so the lanes only queue what they find (the traversal stack
+      // is free until the hierarchy is walked) and then work through their queues in step: the
+      // intersection code runs as often as the fullest queue is long.  The filter runs in single
+      // precision on four entries fetched together; it passes slightly more than the double-precision
+      // band, and the cone's own test decides (src/shape.rs:1089).
       const uint32_t end = S.band_start[cell + 1];
-      for (uint32_t k = S.band_start[cell]; k < end; k++) band(S.bands[S.band_items[k]]);
+      const float fxx = (float)xx, fyy = (float)yy, fzz = (float)zz, fxy = (float)xy, fxz = (float)xz, fyz = (float)yz;
+      const float fdd = (float)dd * (1.0f + 1e-6f);
+      st.clear();
+      auto drain = [&]() {
+        while (__any(st.sp > 0)) {
+          if (st.sp > 0) {
+            const uint32_t prim = st.pop();
+            if (COUNT) cnt.quad_tests++;
+            test_quad(S, S.band_prims[prim], ray, Q, true);
+          }
+        }
+      };
+      for (uint32_t k = S.band_start[cell]; k < end; k += 4) {
+        uint32_t id[4];
+        ConeBandF32 f[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) id[j] = S.band_items[min(k + j, end - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) f[j] = S.bands32[id[j]];
+        if (__any(st.sp + 4 > Stack::ENTRIES)) drain();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float a = fmaf(f[j].q[0], fxx, fmaf(f[j].q[1], fyy, fmaf(f[j].q[2], fzz,
+                          fmaf(f[j].q[3], fxy, fmaf(f[j].q[4], fxz, f[j].q[5] * fyz)))));
+          if (k + j < end && fabsf(a) < 1.0001e-4f + f[j].slack * fdd) st.push(f[j].prim);
+        }
+      }
+      drain();
     } else {
       for (int i = 0; i < S.n_bands; i++) band(S.bands[i]);
     }
@@ -2112,8 +2149,25 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((rc = upload(s, b.csg_unbounded, &s->dev.csg_unbounded))) return rc;
   s->dev.n_csg_unbounded = (int32_t)b.csg_unbounded.size();
   if ((rc = upload(s, b.bands, &s->dev.bands))) return rc;
+  {
+    // single-precision copies: six products and five sums, each within 2^-24 relative, on top of the
+    // rounding of the coefficients and of the direction's products; 2e-6 * sum |q| covers it
+    // several times over
+    std::vector<ConeBandF32> bands32(b.bands.size());
+    for (size_t i = 0; i < b.bands.size(); i++) {
+      double sum = 0;
+      for (int c = 0; c < 6; c++) {
+        bands32[i].q[c] = (float)b.bands[i].q[c];
+        sum += fabs(b.bands[i].q[c]);
+      }
+      bands32[i].slack = std::nextafterf((float)(b.bands[i].slack + 2e-6 * sum), INFINITY);
+      bands32[i].prim = b.bands[i].prim;
+    }
+    if ((rc = upload(s, bands32, &s->dev.bands32))) return rc;
+  }
   if ((rc = upload(s, b.band_prims, &s->dev.band_prims))) return rc;
   s->dev.n_bands = (int32_t)b.bands.size();
+  if (getenv("RT_AMD_TIMING_NO_BANDS")) s->dev.n_bands = 0;  // timing experiment only: drops the cones' parallel-ray hits
   {
     BandGrid grid = build_band_grid(b.bands, (size_t)1 << 29);  // at most 2 GiB of entries
     s->dev.band_grid_n = grid.n;
@@ -2701,6 +2755,8 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
       const double waves = (double)blocks_for(plan.threads[g]) * (BLOCK / 64);
       fprintf(stderr, "[rt_amd] generation %d rays %u: ticks per wave %.0f | raygen %.3f closest %.3f shade %.3f shadow %.3f output %.3f\n",
               g, plan.threads[g], sum / waves, d[0] / sum, d[1] / sum, d[2] / sum, d[3] / sum, d[4] / sum);
+      fprintf(stderr, "[rt_amd]   closest: setup %.3f nodes %.3f tris %.3f quads/gates %.3f | shadow: setup %.3f nodes %.3f tris %.3f quads/gates %.3f\n",
+              d[8] / sum, d[9] / sum, d[10] / sum, d[11] / sum, d[12] / sum, d[13] / sum, d[14] / sum, d[15] / sum);
     }
 #endif
   }

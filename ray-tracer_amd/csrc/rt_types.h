@@ -74,6 +74,15 @@ struct alignas(64) ConeBand {
 };
 static_assert(sizeof(ConeBand) == 64, "ConeBand layout");
 
+// The same quadratic form in single precision with the rounding of that evaluation added to the
+// slack: a first, cheaper filter in front of ConeBand (never rejects what ConeBand accepts).
+struct alignas(32) ConeBandF32 {
+  float q[6];
+  float slack;
+  uint32_t prim;  // index into band_prims
+};
+static_assert(sizeof(ConeBandF32) == 32, "ConeBandF32 layout");
+
 // One reference Group: exact bounding-box gate in group space, then its subtree.
 struct alignas(32) Gate {
   uint32_t root;  // traversal reference of the subtree (REF_NONE when empty)
@@ -150,6 +159,7 @@ struct SceneDev {
   const Gate* gates;
   const QuadPrim* unbounded;  // tested for every ray (planes, infinite cylinders, very large shapes)
   const ConeBand* bands;      // bounded cones: direction pre-filter of their parallel-ray branch
+  const ConeBandF32* bands32;  // first pass of that filter
   const QuadPrim* band_prims;
   const uint32_t* band_start;  // direction grid over bands (band_grid.h), null when band_grid_n == 0
   const uint32_t* band_items;

@@ -54,7 +54,8 @@ def run(pkg, name, path, size, frames, cameras=None, counters=False):
         c = scene.render_device(rgb8_ptr=frame.data_ptr(), counters=True)
         out["per_ray"] = {"node_visits": (c.node_visits + c.shadow_node_visits) / c.rays,
                           "tri_tests": (c.tri_tests + c.shadow_tri_tests) / c.rays,
-                          "quadric_tests": (c.quadric_tests + c.shadow_quadric_tests) / c.rays}
+                          "quadric_tests": (c.quadric_tests + c.shadow_quadric_tests) / c.rays,
+                          "gate_tests": (c.gate_tests + c.shadow_gate_tests) / c.rays}
     print(json.dumps(out), flush=True)
     return out
 
