@@ -628,6 +628,9 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
 // without a finite box, then the 4-wide BVH.  While-while traversal: every lane first descends
 // inner nodes (the nearest hit child stays in a register, the others go on the LDS stack), and
 // only when all lanes of the wave have reached a primitive run or a gate is that work done.
+#ifndef RT_BAND_BATCH
+#define RT_BAND_BATCH 2  // cone-band list entries fetched together
+#endif
 template <class Query, class Stack, bool COUNT>
 DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counters& cnt) {
   RT_TBEGIN(cnt);
@@ -638,27 +641,20 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
   if constexpr (Stack::WITH_CSG)
     for (int i = 0; i < S.n_csg_unbounded; i++) eval_csg<Query, Stack, Stack::THREADS>(S, S.csg_unbounded[i], ray, Q, st, true);
   if (S.n_bands > 0) {
-    const double xx = ray.d.x * ray.d.x, yy = ray.d.y * ray.d.y, zz = ray.d.z * ray.d.z;
-    const double xy = ray.d.x * ray.d.y, xz = ray.d.x * ray.d.z, yz = ray.d.y * ray.d.z;
-    const double dd = xx + yy + zz;
-    auto band = [&](const ConeBand& cb) {
-      double a = fma(cb.q[0], xx, fma(cb.q[1], yy, fma(cb.q[2], zz, fma(cb.q[3], xy, fma(cb.q[4], xz, cb.q[5] * yz)))));
-      if (fabs(a) < FEQ_EPSILON * (1.0 + 1e-6) + cb.slack * dd) {
-        if (COUNT) cnt.quad_tests++;
-        test_quad(S, S.band_prims[cb.prim], ray, Q, true);
-      }
-    };
+    const double dd = ray.d.x * ray.d.x + ray.d.y * ray.d.y + ray.d.z * ray.d.z;
     if (S.band_grid_n > 0 && dd >= 1.0 - 1e-6) {
       // cell of the direction on the sign-folded cube map; the grid was built for |d| >= 1 - 1e-6
       const int n = S.band_grid_n;
-      int m = zz > yy ? 2 : 1;
-      m = xx >= (m == 2 ? zz : yy) ? 0 : m;
-      const double dm = m == 0 ? ray.d.x : (m == 1 ? ray.d.y : ray.d.z);
-      const double da = m == 0 ? ray.d.y : (m == 1 ? ray.d.z : ray.d.x);
-      const double dc = m == 0 ? ray.d.z : (m == 1 ? ray.d.x : ray.d.y);
-      const float inv = __builtin_amdgcn_rcpf((float)dm);
+      const float fx = (float)ray.d.x, fy = (float)ray.d.y, fz = (float)ray.d.z;
+      const float fxx = fx * fx, fyy = fy * fy, fzz = fz * fz, fxy = fx * fy, fxz = fx * fz, fyz = fy * fz;
+      int m = fzz > fyy ? 2 : 1;
+      m = fxx >= (m == 2 ? fzz : fyy) ? 0 : m;
+      const float dm = m == 0 ? fx : (m == 1 ? fy : fz);
+      const float da = m == 0 ? fy : (m == 1 ? fz : fx);
+      const float dc = m == 0 ? fz : (m == 1 ? fx : fy);
+      const float inv = __builtin_amdgcn_rcpf(dm);
       const float half_n = 0.5f * (float)n;
-      int iu = (int)floorf(((float)da * inv + 1.0f) * half_n), iv = (int)floorf(((float)dc * inv + 1.0f) * half_n);
+      int iu = (int)floorf((da * inv + 1.0f) * half_n), iv = (int)floorf((dc * inv + 1.0f) * half_n);
       iu = iu < 0 ? 0 : (iu >= n ? n - 1 : iu);
       iv = iv < 0 ? 0 : (iv >= n ? n - 1 : iv);
       const uint32_t cell = ((uint32_t)m * n + iv) * n + iu;
@@ -668,11 +664,11 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       // finds one at almost every step), so the lanes only queue what they find (the traversal stack
       // is free until the hierarchy is walked) and then work through their queues in step: the
       // intersection code runs as often as the fullest queue is long.  The filter runs in single
-      // precision on four entries fetched together; it passes slightly more than the double-precision
-      // band, and the cone's own test decides (src/shape.rs:1089).
+      // precision (it passes slightly more than the double-precision band; the cone's own test
+      // decides, src/shape.rs:1089) and keeps few registers alive, so that scenes without cones do
+      // not pay for it in spills.
       const uint32_t end = S.band_start[cell + 1];
-      const float fxx = (float)xx, fyy = (float)yy, fzz = (float)zz, fxy = (float)xy, fxz = (float)xz, fyz = (float)yz;
-      const float fdd = (float)dd * (1.0f + 1e-6f);
+      const float fdd = (fxx + fyy + fzz) * (1.0f + 1e-6f);
       st.clear();
       auto drain = [&]() {
         while (__any(st.sp > 0)) {
@@ -683,16 +679,16 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
           }
         }
       };
-      for (uint32_t k = S.band_start[cell]; k < end; k += 4) {
-        uint32_t id[4];
-        ConeBandF32 f[4];
+      for (uint32_t k = S.band_start[cell]; k < end; k += RT_BAND_BATCH) {
+        uint32_t id[RT_BAND_BATCH];
+        ConeBandF32 f[RT_BAND_BATCH];
 #pragma unroll
-        for (int j = 0; j < 4; j++) id[j] = S.band_items[min(k + j, end - 1)];
+        for (int j = 0; j < RT_BAND_BATCH; j++) id[j] = S.band_items[min(k + j, end - 1)];
 #pragma unroll
-        for (int j = 0; j < 4; j++) f[j] = S.bands32[id[j]];
-        if (__any(st.sp + 4 > Stack::ENTRIES)) drain();
+        for (int j = 0; j < RT_BAND_BATCH; j++) f[j] = S.bands32[id[j]];
+        if (__any(st.sp + RT_BAND_BATCH > Stack::ENTRIES)) drain();
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < RT_BAND_BATCH; j++) {
           const float a = fmaf(f[j].q[0], fxx, fmaf(f[j].q[1], fyy, fmaf(f[j].q[2], fzz,
                           fmaf(f[j].q[3], fxy, fmaf(f[j].q[4], fxz, f[j].q[5] * fyz)))));
           if (k + j < end && fabsf(a) < 1.0001e-4f + f[j].slack * fdd) st.push(f[j].prim);
@@ -700,7 +696,16 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       }
       drain();
     } else {
-      for (int i = 0; i < S.n_bands; i++) band(S.bands[i]);
+      const double xx = ray.d.x * ray.d.x, yy = ray.d.y * ray.d.y, zz = ray.d.z * ray.d.z;
+      const double xy = ray.d.x * ray.d.y, xz = ray.d.x * ray.d.z, yz = ray.d.y * ray.d.z;
+      for (int i = 0; i < S.n_bands; i++) {
+        const ConeBand& cb = S.bands[i];
+        double a = fma(cb.q[0], xx, fma(cb.q[1], yy, fma(cb.q[2], zz, fma(cb.q[3], xy, fma(cb.q[4], xz, cb.q[5] * yz)))));
+        if (fabs(a) < FEQ_EPSILON * (1.0 + 1e-6) + cb.slack * dd) {
+          if (COUNT) cnt.quad_tests++;
+          test_quad(S, S.band_prims[cb.prim], ray, Q, true);
+        }
+      }
     }
   }
   if (S.root == REF_NONE || Q.done()) return;
@@ -2150,9 +2155,9 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   s->dev.n_csg_unbounded = (int32_t)b.csg_unbounded.size();
   if ((rc = upload(s, b.bands, &s->dev.bands))) return rc;
   {
-    // single-precision copies: six products and five sums, each within 2^-24 relative, on top of the
-    // rounding of the coefficients and of the direction's products; 2e-6 * sum |q| covers it
-    // several times over
+    // single-precision copies: the direction's components are rounded to single (2^-24 each, so
+    // 2^-23 per product), then six products and five sums within 2^-24 relative each, on top of the
+    // rounding of the coefficients: below 1e-6 * sum |q| in all; 4e-6 * sum |q| is added to the slack
     std::vector<ConeBandF32> bands32(b.bands.size());
     for (size_t i = 0; i < b.bands.size(); i++) {
       double sum = 0;
@@ -2160,7 +2165,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
         bands32[i].q[c] = (float)b.bands[i].q[c];
         sum += fabs(b.bands[i].q[c]);
       }
-      bands32[i].slack = std::nextafterf((float)(b.bands[i].slack + 2e-6 * sum), INFINITY);
+      bands32[i].slack = std::nextafterf((float)(b.bands[i].slack + 4e-6 * sum), INFINITY);
       bands32[i].prim = b.bands[i].prim;
     }
     if ((rc = upload(s, bands32, &s->dev.bands32))) return rc;
