@@ -53,6 +53,31 @@ __device__ __forceinline__ int ppm_step(int col, int lr, int lg, int lb) {
 
 __device__ __forceinline__ int clamp_state(int col) { return col < STATES ? col : STATES; }
 
+// The same step with everything that depends on the pixel alone worked out once per wave (the pixel
+// is the same for all lanes, so these live in scalar registers) and no branches per state: seven
+// vector instructions.  Valid for col >= 2, which is every column but the one before the first pixel.
+struct PixelStep {
+  int grow, t1, t2, t3, r1, r2, r3;
+  __device__ __forceinline__ explicit PixelStep(uint32_t lens) {
+    const int lr = lens & 3, lg = (lens >> 2) & 3, lb = (lens >> 4) & 3;
+    grow = lr + lg + lb + 3;
+    t1 = 70 - lr; t2 = 70 - lr - lg; t3 = 70 - lr - lg - lb;
+    r1 = lr + lg + lb + 3; r2 = lg + lb + 2; r3 = lb + 1;
+  }
+  __device__ __forceinline__ int operator()(int col) const {
+    int next = col + grow;
+    next = col > t3 ? r3 : next;
+    next = col > t2 ? r2 : next;
+    next = col > t1 ? r1 : next;  // t1 >= t2 >= t3: the first condition of the reference wins
+    return next;
+  }
+};
+
+// lens of pixel k of the wave, as a scalar
+__device__ __forceinline__ uint32_t lens_of(uint32_t lens, int k) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)lens, k);
+}
+
 // digit counts of pixel p packed as lr | lg << 2 | lb << 4 (0 for a lane beyond the image)
 __device__ __forceinline__ uint32_t pixel_lens(const uint8_t* rgb8, uint64_t p, uint64_t n, uint32_t* rgb) {
   if (p >= n) {
@@ -97,12 +122,19 @@ __global__ void __launch_bounds__(CHUNK* WAVES_PER_BLOCK)
   if (chunk == 0) total -= 1;  // the first pixel of the file has no separator in front
   const int count = (int)min((uint64_t)CHUNK, n - chunk * CHUNK);
   int s0 = (int)lane + 1, s1 = (int)lane + 65;
-  for (int k = 0; k < count; k++) {
-    const uint32_t l = __shfl(lens, k, 64);
+  {  // the first pixel with the general step: column 1 is among the states
+    const uint32_t l = lens_of(lens, 0);
     const int lr = l & 3, lg = (l >> 2) & 3, lb = (l >> 4) & 3;
     s0 = ppm_step(s0, lr, lg, lb);
-    s1 = clamp_state(ppm_step(s1, lr, lg, lb));
+    s1 = ppm_step(s1, lr, lg, lb);
   }
+#pragma unroll 8
+  for (int k = 1; k < count; k++) {
+    const PixelStep step(lens_of(lens, k));
+    s0 = step(s0);
+    s1 = step(s1);
+  }
+  s1 = clamp_state(s1);
   maps[chunk * STATES + lane] = (uint8_t)s0;
   maps[chunk * STATES + 64 + lane] = (uint8_t)s1;
   if (lane == 0) chunk_bytes[chunk] = total;
