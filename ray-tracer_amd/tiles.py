@@ -70,48 +70,68 @@ class FrameGather:
     """Collects the parts of a frame on rank 0.
 
     Every rank renders its part in the compact layout into `mine[k]` (k < depth: several buffers so that
-    frame n + 1 can be rendered while frame n is still being gathered); `__call__(k, frame)` gathers
-    the buffers to rank 0 and, there, scatters them into the (H, W, 3) uint8 `frame` with one indexed
-    copy.  With one rank nothing is exchanged: the frame is rendered in place.
+    frame n + 1 can be rendered while frame n is still being gathered).  The buffers form depth / bucket
+    buckets of `bucket` consecutive frames; `gather_bucket(b)` sends a whole bucket to rank 0 in one
+    gather and, there, scatters it into the (H, W, 3) uint8 frames of the bucket with one indexed copy:
+    when a frame renders faster than a collective starts, a rank moves several frames per collective.
+    `__call__(k)` is the per-frame form (bucket = 1).  With one rank nothing is exchanged: the frame is
+    rendered in place.
     """
 
-    def __init__(self, width, height, device, rank, world, backend=None, depth=2):
+    def __init__(self, width, height, device, rank, world, backend=None, depth=2, bucket=1):
         self.rank, self.world, self.device = rank, world, device
         self.width, self.height = width, height
         self.backend = backend or (dist.get_backend() if world > 1 else None)
+        self.depth, self.bucket = depth, bucket
+        if depth % bucket:
+            raise ValueError("depth %d is not a multiple of bucket %d" % (depth, bucket))
         if world == 1:
             return
         n_pix = width * height
         idx = [compact_pixel_index(width, height, p, world, outside=n_pix) for p in range(world)]
         self.slots = [int(i.numel()) for i in idx]
         n_max = max(self.slots)
-        self.mine = [torch.zeros((n_max, 3), dtype=torch.uint8, device=device) for _ in range(depth)]
+        n_buckets = depth // bucket
+        self.mine_all = torch.zeros((n_buckets, bucket, n_max, 3), dtype=torch.uint8, device=device)
+        self.mine = [self.mine_all[k // bucket, k % bucket] for k in range(depth)]
         if rank == 0:
-            # one index for all parts, padded slots and out-of-image slots land on a spare row
-            pad = torch.full((world, n_max), n_pix, dtype=torch.int64)
+            # one index for all parts and all frames of a bucket; padded slots and out-of-image slots
+            # land on the spare row that follows every frame
+            pad = torch.full((world, bucket, n_max), n_pix, dtype=torch.int64)
             for p in range(world):
-                pad[p, : self.slots[p]] = idx[p]
+                pad[p, :, : self.slots[p]] = idx[p][None, :]
+            pad += (torch.arange(bucket, dtype=torch.int64) * (n_pix + 1))[None, :, None]
             self.index = pad.reshape(-1).to(device)
-            self.recv = [torch.zeros((world, n_max, 3), dtype=torch.uint8, device=device) for _ in range(depth)]
-            self.canvas = [torch.zeros((n_pix + 1, 3), dtype=torch.uint8, device=device) for _ in range(depth)]
+            self.recv = [torch.zeros((world, bucket, n_max, 3), dtype=torch.uint8, device=device)
+                         for _ in range(n_buckets)]
+            self.canvas = [torch.zeros((bucket, n_pix + 1, 3), dtype=torch.uint8, device=device)
+                           for _ in range(n_buckets)]
 
     def frame(self, k):
-        """(H, W, 3) view of buffer k on rank 0 after __call__(k)."""
-        return self.canvas[k][:-1].view(self.height, self.width, 3)
+        """(H, W, 3) view of buffer k on rank 0 after its bucket was gathered."""
+        return self.canvas[k // self.bucket][k % self.bucket, :-1].view(self.height, self.width, 3)
+
+    def gather_bucket(self, b):
+        """Gathers frames b * bucket ... (b + 1) * bucket - 1 on rank 0 (a collective: every rank calls it)."""
+        if self.world == 1:
+            return
+        mine = self.mine_all[b]
+        if self.backend == "gloo" and mine.is_cuda:
+            # rehearsal on a machine without RCCL peers: stage through host memory
+            mine = mine.cpu()
+            parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(mine, parts, dst=0)
+            if self.rank == 0:
+                self.recv[b].copy_(torch.stack(parts))
+        else:
+            dist.gather(mine, list(self.recv[b].unbind(0)) if self.rank == 0 else None, dst=0)
+        if self.rank == 0:
+            self.canvas[b].view(-1, 3).index_copy_(0, self.index, self.recv[b].view(-1, 3))
 
     def __call__(self, k):
         if self.world == 1:
             return None
-        if self.backend == "gloo" and self.mine[k].is_cuda:
-            # rehearsal on a machine without RCCL peers: stage through host memory
-            mine = self.mine[k].cpu()
-            parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(mine, parts, dst=0)
-            if self.rank == 0:
-                self.recv[k].copy_(torch.stack(parts))
-        else:
-            dist.gather(self.mine[k], list(self.recv[k].unbind(0)) if self.rank == 0 else None, dst=0)
-        if self.rank == 0:
-            self.canvas[k].index_copy_(0, self.index, self.recv[k].view(-1, 3))
-            return self.frame(k)
-        return None
+        if self.bucket != 1:
+            raise ValueError("per-frame gather needs bucket = 1")
+        self.gather_bucket(k)
+        return self.frame(k) if self.rank == 0 else None

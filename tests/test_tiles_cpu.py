@@ -57,6 +57,19 @@ def _worker(rank, world, port, w, h, out):
             frame = gather(k)
             if rank == 0:
                 ok = ok and bool(torch.equal(frame, truth))
+        # buckets: two buckets of three frames, each frame different, one gather per bucket
+        bucketed = pkg.tiles.FrameGather(w, h, "cpu", rank, world, depth=6, bucket=3)
+        idx = pkg.tiles.compact_pixel_index(w, h, rank, world, outside=-1)
+        inside = idx >= 0
+        for b in (0, 1, 0):
+            for f in range(3):
+                k = 3 * b + f
+                bucketed.mine[k].fill_(255)
+                bucketed.mine[k][: idx.numel()][inside] = (truth + (k + b)).view(-1, 3)[idx[inside]]
+            bucketed.gather_bucket(b)
+            if rank == 0:
+                for f in range(3):
+                    ok = ok and bool(torch.equal(bucketed.frame(3 * b + f), truth + (3 * b + f + b)))
         if rank == 0:
             out.put(ok)
         dist.barrier()
