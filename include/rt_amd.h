@@ -151,10 +151,23 @@ typedef struct rt_camera {
   double inv[16];
 } rt_camera;
 
+/* Transform chains.  `shape::intersect` moves a ray into object space level by level: every enclosing
+ * group or CSG operator applies its own `transform_inverse` to the ray its parent handed down
+ * (src/shape.rs:1467-1470, 1213-1218, 1339-1354).  Applying the product `ray_inv` / `to_local` once is
+ * bit-identical to that only while at most one matrix of the chain differs from the identity.  For a
+ * shape or group with two or more, the host lists those non-identity local inverses, outermost
+ * first, in chain_mats and points at them from xform_chain / gate_chain; the device then applies
+ * them one after the other, as the reference does.  An entry with count 0 (or a null table) means
+ * "the product is exact". */
+typedef struct rt_chain_ref {
+  int32_t first; /* index of the first matrix in chain_mats */
+  int32_t count; /* 0: none */
+} rt_chain_ref;
+
 typedef struct rt_scene_desc {
   rt_light light;
   int32_t n_leaves, n_gates, n_xforms, n_triangles, n_materials, n_patterns;
-  int32_t n_csg, reserved;
+  int32_t n_csg, n_chain_mats;
   const rt_csg* csg;
   const rt_leaf* leaves;
   const rt_gate* gates;
@@ -162,6 +175,9 @@ typedef struct rt_scene_desc {
   const rt_triangle* triangles;
   const rt_material* materials;
   const rt_pattern* patterns;
+  const double* chain_mats;        /* n_chain_mats x 16, row-major; may be null when n_chain_mats == 0 */
+  const rt_chain_ref* xform_chain; /* n_xforms entries, or null */
+  const rt_chain_ref* gate_chain;  /* n_gates entries, or null */
 } rt_scene_desc;
 
 /* Ray counts use the reference's unit: one ray = one `World::intersect` query

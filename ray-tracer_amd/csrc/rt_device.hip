@@ -257,8 +257,38 @@ DEV void gate_axis(double mn, double mx, double origin, double direction, double
     tmax = s;
   }
 }
-DEV bool gate_passes(const Gate& g, const Ray& world_ray) {
-  Ray r = transform_ray(g.m, world_ray);
+// A ray taken through a transform chain: one local inverse after the other, outermost first, as the
+// nested calls of shape::intersect do (src/shape.rs:1467-1470).
+DEV Ray chain_ray(const SceneDev& S, uint32_t first, uint32_t len, Ray r) {
+  for (uint32_t k = 0; k < len; k++) r = transform_ray(S.chain_mats + 12 * (size_t)(first + k), r);
+  return r;
+}
+// GENERAL: the kernels built for scenes with CSG operators or transform chains.
+template <bool GENERAL>
+DEV Ray quad_ray(const SceneDev& S, const QuadPrim& q, const Ray& ray) {
+  if constexpr (GENERAL) {
+    if (q.type & QUAD_CHAIN) {
+      const uint32_t x = (uint32_t)S.leaves[q.leaf].xform;
+      return chain_ray(S, S.xform_chain[2 * x], S.xform_chain[2 * x + 1], ray);
+    }
+  }
+  return transform_ray(q.m, ray);
+}
+template <bool GENERAL>
+DEV Ray tri_ray(const SceneDev& S, const TriIsect& tr, const Ray& ray) {  // tr.xform >= 0
+  if constexpr (GENERAL) {
+    if (tr.xform & TRI_XFORM_CHAIN) {
+      const uint32_t x = (uint32_t)(tr.xform & ~TRI_XFORM_CHAIN);
+      return chain_ray(S, S.xform_chain[2 * x], S.xform_chain[2 * x + 1], ray);
+    }
+  }
+  return transform_ray(S.xforms[tr.xform].ray_inv, ray);
+}
+template <bool GENERAL>
+DEV bool gate_passes(const SceneDev& S, const Gate& g, const Ray& world_ray) {
+  Ray r;
+  if (GENERAL && g.chain_len) r = chain_ray(S, g.chain_first, g.chain_len, world_ray);
+  else r = transform_ray(g.m, world_ray);
   double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
   gate_axis(g.bmin[0], g.bmax[0], r.o.x, r.d.x, xtmin, xtmax);
   gate_axis(g.bmin[1], g.bmax[1], r.o.y, r.d.y, ytmin, ytmax);
@@ -500,11 +530,11 @@ DEV void slab4(const RayBox& rb, float qhi, const F4& nx, const F4& ny, const F4
   }
 }
 
-template <class Query>
+template <class Query, bool GENERAL>
 DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& Q, bool check_gates) {
   if (check_gates) {
     for (int g = q.gate; g >= 0; g = S.gates[g].parent)
-      if (!gate_passes(S.gates[g], ray)) return;
+      if (!gate_passes<GENERAL>(S, S.gates[g], ray)) return;
   }
   double t[4];
 #ifndef RT_NO_PLANE_FAST
@@ -518,7 +548,7 @@ DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& 
     return;
   }
 #endif
-  Ray local = transform_ray(q.m, ray);  // src/shape.rs:1468
+  Ray local = quad_ray<GENERAL>(S, q, ray);  // src/shape.rs:1468
   int n = intersect_quadric(q.type, q.closed, q.minimum, q.maximum, local, t);
   if (n) Q.leaf_ts(q.leaf, n, t);
 }
@@ -537,7 +567,7 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
   if (!list) return;
   if (outer_gates)
     for (int g = R.gate; g >= 0; g = S.gates[g].parent)
-      if (!gate_passes(S.gates[g], ray)) return;
+      if (!gate_passes<true>(S, S.gates[g], ray)) return;
   auto put = [&](int e, double t, uint32_t who) {
     list[(3 * e + 0) * BLOCK_] = (uint32_t)__double2loint(t);
     list[(3 * e + 1) * BLOCK_] = (uint32_t)__double2hiint(t);
@@ -550,7 +580,7 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
     const CsgLeaf L = S.csg_leaves[R.first_leaf + j];
     bool open = true;
     for (int g = L.gate; g != R.gate && g >= 0; g = S.gates[g].parent)  // groups between the root and the leaf
-      if (!gate_passes(S.gates[g], ray)) {
+      if (!gate_passes<true>(S, S.gates[g], ray)) {
         open = false;
         break;
       }
@@ -561,12 +591,12 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
     if ((L.ref >> 30) == KIND_TRI) {
       const TriIsect& tr = S.tris[idx];
       double u, v;
-      bool hit = tr.xform >= 0 ? intersect_triangle(tr, transform_ray(S.xforms[tr.xform].ray_inv, ray), t[0], u, v)
+      bool hit = tr.xform >= 0 ? intersect_triangle(tr, tri_ray<true>(S, tr, ray), t[0], u, v)
                                : intersect_triangle(tr, ray, t[0], u, v);
       m = hit ? 1 : 0;
     } else {
       const QuadPrim& q = S.quads[idx];
-      m = intersect_quadric(q.type, q.closed, q.minimum, q.maximum, transform_ray(q.m, ray), t);
+      m = intersect_quadric(q.type, q.closed, q.minimum, q.maximum, quad_ray<true>(S, q, ray), t);
     }
     for (int k = 0; k < m; k++) {
       if (!(t[k] == t[k]) || n >= CSG_MAX_HITS) continue;  // NaN never orders (the reference's sort would panic)
@@ -615,7 +645,7 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
     if ((L.ref >> 30) == KIND_TRI) {
       const TriIsect& tr = S.tris[idx];
       double tt, u, v;  // again, for the barycentric coordinates of a smooth triangle
-      bool hit = tr.xform >= 0 ? intersect_triangle(tr, transform_ray(S.xforms[tr.xform].ray_inv, ray), tt, u, v)
+      bool hit = tr.xform >= 0 ? intersect_triangle(tr, tri_ray<true>(S, tr, ray), tt, u, v)
                                : intersect_triangle(tr, ray, tt, u, v);
       if (hit) Q.leaf_tri(tr.leaf, tt, u, v);
     } else {
@@ -636,7 +666,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
   RT_TBEGIN(cnt);
   for (int i = 0; i < S.n_unbounded; i++) {
     if (COUNT) cnt.quad_tests++;
-    test_quad(S, S.unbounded[i], ray, Q, true);
+    test_quad<Query, Stack::WITH_CSG>(S, S.unbounded[i], ray, Q, true);
   }
   if constexpr (Stack::WITH_CSG)
     for (int i = 0; i < S.n_csg_unbounded; i++) eval_csg<Query, Stack, Stack::THREADS>(S, S.csg_unbounded[i], ray, Q, st, true);
@@ -675,7 +705,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
           if (st.sp > 0) {
             const uint32_t prim = st.pop();
             if (COUNT) cnt.quad_tests++;
-            test_quad(S, S.band_prims[prim], ray, Q, true);
+            test_quad<Query, Stack::WITH_CSG>(S, S.band_prims[prim], ray, Q, true);
           }
         }
       };
@@ -703,7 +733,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
         double a = fma(cb.q[0], xx, fma(cb.q[1], yy, fma(cb.q[2], zz, fma(cb.q[3], xy, fma(cb.q[4], xz, cb.q[5] * yz)))));
         if (fabs(a) < FEQ_EPSILON * (1.0 + 1e-6) + cb.slack * dd) {
           if (COUNT) cnt.quad_tests++;
-          test_quad(S, S.band_prims[cb.prim], ray, Q, true);
+          test_quad<Query, Stack::WITH_CSG>(S, S.band_prims[cb.prim], ray, Q, true);
         }
       }
     }
@@ -790,7 +820,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
         pass = true;
       } else {
         if (COUNT) cnt.gate_tests++;
-        pass = gate_passes(g, ray);
+        pass = gate_passes<Stack::WITH_CSG>(S, g, ray);
       }
       cur = pass ? g.root : st.pop_or_none();
       RT_TSTAMP(cnt, 3);
@@ -804,7 +834,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
         double t, u, v;
         bool hit;
         if (tr.xform >= 0) {
-          Ray local = transform_ray(S.xforms[tr.xform].ray_inv, ray);
+          Ray local = tri_ray<Stack::WITH_CSG>(S, tr, ray);
           hit = intersect_triangle(tr, local, t, u, v);
         } else {
           hit = intersect_triangle(tr, ray, t, u, v);
@@ -815,7 +845,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     } else {
       for (uint32_t i = 0; i < count; i++) {
         if (COUNT) cnt.quad_tests++;
-        test_quad(S, S.quads[first + i], ray, Q, false);
+        test_quad<Query, Stack::WITH_CSG>(S, S.quads[first + i], ray, Q, false);
       }
       RT_TSTAMP(cnt, 3);
     }
@@ -1703,13 +1733,22 @@ struct SceneBuild {
   std::vector<int> tri_xform;  // device xform index or -1 (identity)
   int stack_need = 1;
 
+  bool xform_has_chain(int x) const { return d->xform_chain && d->xform_chain[x].count > 0; }
+  void gate_chain(int gi, Gate& g) const {
+    g.chain_first = g.chain_len = 0;
+    if (d->gate_chain && d->gate_chain[gi].count > 0) {
+      g.chain_first = (uint32_t)d->gate_chain[gi].first;
+      g.chain_len = (uint32_t)d->gate_chain[gi].count;
+    }
+  }
+
   QuadPrim make_quad(int li) const {
     const rt_leaf& L = d->leaves[li];
     QuadPrim q{};
     copy3x4(q.m, d->xforms[L.xform].ray_inv);
     q.minimum = L.minimum;
     q.maximum = L.maximum;
-    q.type = L.type;
+    q.type = L.type | (xform_has_chain(L.xform) ? QUAD_CHAIN : 0);
     q.closed = L.closed;
     q.leaf = li;
     q.gate = L.gate;
@@ -1727,6 +1766,7 @@ struct SceneBuild {
     }
     ti.leaf = li;
     ti.xform = is_identity(d->xforms[L.xform].ray_inv) ? -1 : L.xform;
+    if (xform_has_chain(L.xform)) ti.xform = L.xform | TRI_XFORM_CHAIN;
     return ti;
   }
 
@@ -1869,6 +1909,7 @@ struct SceneBuild {
     const rt_gate& G = d->gates[gi];
     Gate& g = gates[gi];
     copy3x4(g.m, G.to_local);
+    gate_chain(gi, g);
     for (int a = 0; a < 3; a++) {
       g.bmin[a] = G.bmin[a];
       g.bmax[a] = G.bmax[a];
@@ -1970,6 +2011,19 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
       return fail(RT_ERR_INVALID, "gate parent must precede its children");
   }
   if (d->n_csg < 0 || (d->n_csg > 0 && !d->csg)) return fail(RT_ERR_INVALID, "bad CSG operator list");
+  if (d->n_chain_mats < 0 || (d->n_chain_mats > 0 && !d->chain_mats)) return fail(RT_ERR_INVALID, "bad transform chain list");
+  for (int i = 0; i < d->n_chain_mats; i++)
+    if (!affine(d->chain_mats + 16 * (size_t)i)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) matrix in a transform chain");
+  bool any_chain = false;
+  for (int pass = 0; pass < 2; pass++) {
+    const rt_chain_ref* refs = pass ? d->gate_chain : d->xform_chain;
+    const int n = pass ? d->n_gates : d->n_xforms;
+    for (int i = 0; refs && i < n; i++) {
+      if (refs[i].count < 0 || refs[i].first < 0 || (int64_t)refs[i].first + refs[i].count > d->n_chain_mats)
+        return fail(RT_ERR_INVALID, "transform chain out of range");
+      any_chain = any_chain || refs[i].count > 0;
+    }
+  }
   for (int i = 0; i < d->n_csg; i++) {
     const rt_csg& c = d->csg[i];
     if (c.op < RT_CSG_UNION || c.op > RT_CSG_DIFFERENCE) return fail(RT_ERR_INVALID, "unknown CSG operator");
@@ -2033,6 +2087,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
       // a group below a CSG operator: only its gate record is needed (eval_csg tests it per leaf)
       Gate& g = b.gates[i];
       copy3x4(g.m, G.to_local);
+      b.gate_chain(i, g);
       for (int a = 0; a < 3; a++) {
         g.bmin[a] = G.bmin[a];
         g.bmax[a] = G.bmax[a];
@@ -2086,7 +2141,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   tris.insert(tris.end(), b.csg_tris.begin(), b.csg_tris.end());
   quads.insert(quads.end(), b.csg_quads.begin(), b.csg_quads.end());
   if (tris.size() > MAX_RUN_FIRST || quads.size() > MAX_RUN_FIRST) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
-  s->has_csg = !b.csg_roots.empty();
+  s->has_csg = !b.csg_roots.empty() || any_chain;  // either needs the general kernels
   s->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
   // ---- shading tables
@@ -2183,6 +2238,17 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   }
   if ((rc = upload(s, leaves, &s->dev.leaves))) return rc;
   if ((rc = upload(s, xforms, &s->dev.xforms))) return rc;
+  if (any_chain) {
+    std::vector<double> chain_mats((size_t)d->n_chain_mats * 12);
+    for (int i = 0; i < d->n_chain_mats; i++) copy3x4(&chain_mats[(size_t)i * 12], d->chain_mats + 16 * (size_t)i);
+    std::vector<uint32_t> xform_chain((size_t)d->n_xforms * 2, 0u);
+    for (int i = 0; d->xform_chain && i < d->n_xforms; i++) {
+      xform_chain[2 * (size_t)i] = (uint32_t)d->xform_chain[i].first;
+      xform_chain[2 * (size_t)i + 1] = (uint32_t)d->xform_chain[i].count;
+    }
+    if ((rc = upload(s, chain_mats, &s->dev.chain_mats))) return rc;
+    if ((rc = upload(s, xform_chain, &s->dev.xform_chain))) return rc;
+  }
   if ((rc = upload(s, tri_shade, &s->dev.tri_shade))) return rc;
   if ((rc = upload(s, mats, &s->dev.materials))) return rc;
   if ((rc = upload(s, pats, &s->dev.patterns))) return rc;

@@ -64,6 +64,16 @@ static_assert(sizeof(QuadPrim) == 128, "QuadPrim must be one cache line");
 // ray), and in the band list with QUAD_ONLY_PARALLEL, which every ray scans by direction only.
 constexpr int32_t QUAD_TYPE_MASK = 0xFF, QUAD_SKIP_PARALLEL = 0x100, QUAD_ONLY_PARALLEL = 0x200;
 
+// The reference moves a ray into object space level by level: every enclosing group or CSG operator
+// applies its own transform_inverse to the ray its parent handed down (src/shape.rs:1467-1470,
+// 1213-1218).  One matrix product applied once gives the same ray only up to rounding as soon as two
+// of those matrices differ from the identity, and a last-bit difference in t can turn a grazing
+// reflection or shadow ray.  Such a shape or group carries a chain: its non-identity local inverses,
+// outermost first, applied one after the other (SceneDev::chain_mats).  QUAD_CHAIN marks a QuadPrim
+// whose chain is found through its leaf's transform record, TRI_XFORM_CHAIN the same in TriIsect::xform.
+constexpr int32_t QUAD_CHAIN = 0x400;
+constexpr int32_t TRI_XFORM_CHAIN = 0x40000000;
+
 // Direction pre-filter of one band-list cone: a(d) = q . (dx^2, dy^2, dz^2, dx dy, dx dz, dy dz) is the
 // cone's quadratic coefficient for a world-space direction d, up to rounding covered by slack |d|^2.
 struct alignas(64) ConeBand {
@@ -94,8 +104,10 @@ struct alignas(32) Gate {
   uint32_t csg;  // 0: a group; k + 1: stands for CSG root k, nothing else of the record is used
   double m[12];  // rows 0..2 of to_local
   double bmin[3], bmax[3];
+  uint32_t chain_first, chain_len;  // chain_len > 0: the matrices to apply instead of m, see QUAD_CHAIN
+  uint32_t pad[6];
 };
-static_assert(sizeof(Gate) == 160, "Gate layout");
+static_assert(sizeof(Gate) == 192, "Gate layout");
 
 // CSG (reference src/shape.rs:1339-1354, src/intersect.rs:278-328).  A root is a maximal operator
 // tree; a ray that reaches it collects the intersections of all leaves below (at most
@@ -172,6 +184,8 @@ struct SceneDev {
   const TriShade* tri_shade;
   const MaterialDev* materials;
   const PatternDev* patterns;
+  const double* chain_mats;     // 12 doubles (rows 0..2) per matrix
+  const uint32_t* xform_chain;  // per transform record: first matrix, count (0: the product is exact)
   uint32_t root;      // for rays that take every gate test
   uint32_t root_alt;  // for rays that may skip skippable gates
   int32_t n_unbounded;

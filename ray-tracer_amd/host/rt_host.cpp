@@ -764,9 +764,39 @@ struct Flattener {
     return false;
   }
 
+  // The non-identity local inverses from the top level down to the shape being walked, outermost
+  // first: the matrices shape::intersect applies to a ray one after the other (src/shape.rs:1467-1470).
+  // Multiplying by the identity changes nothing, so with fewer than two of them the product ray_inv
+  // applied once gives the same ray bit for bit; with two or more the device has to follow the chain.
+  std::vector<Mat4> chain;
+  rt_chain_ref emit_chain() {
+    rt_chain_ref r{0, 0};
+    if (chain.size() < 2) return r;
+    r.first = (int32_t)(out.chain_mats.size() / 16);
+    r.count = (int32_t)chain.size();
+    for (const Mat4& m : chain) out.chain_mats.insert(out.chain_mats.end(), m.m, m.m + 16);
+    return r;
+  }
+  struct ChainLevel {  // pushes a level's local inverse for the lifetime of the walk below it
+    std::vector<Mat4>& chain;
+    bool pushed;
+    static bool same_as_identity(const Mat4& m) {  // by value: the cofactor inverse of the identity holds -0.0
+      for (int i = 0; i < 16; i++)
+        if (m.m[i] != (i % 5 == 0 ? 1.0 : 0.0)) return false;
+      return true;
+    }
+    ChainLevel(std::vector<Mat4>& c, const Mat4& local_inv) : chain(c), pushed(!same_as_identity(local_inv)) {
+      if (pushed) chain.push_back(local_inv);
+    }
+    ~ChainLevel() {
+      if (pushed) chain.pop_back();
+    }
+  };
+
   void walk(const Shape& s, const Mat4& ray_acc, bool has_parent, const Mat4& parent, int gate, Share* share, int csg = -1) {
     Mat4 local_inv = s.transform.inverse_or_panic("Shape transform should have an inverse.");
     Mat4 ray_inv = has_parent ? local_inv * ray_acc : local_inv;
+    ChainLevel level(chain, local_inv);
     if (s.kind == Shape::Csg) {
       // a transform level like a group, without the bounding-box gate (src/shape.rs:1339-1354)
       if (left_operands.size() >= 32) throw std::invalid_argument("CSG operators nested deeper than 32 levels");
@@ -794,6 +824,7 @@ struct Flattener {
       memcpy(g.bmin, b.lo, sizeof(g.bmin));
       memcpy(g.bmax, b.hi, sizeof(g.bmax));
       out.gates.push_back(g);
+      out.gate_chain.push_back(emit_chain());
       int gi = (int)out.gates.size() - 1;
       Mat4 child_parent = has_parent ? parent * s.transform : s.transform;
       Share group_share;
@@ -828,6 +859,7 @@ struct Flattener {
       memcpy(X.full_inv, full.m, sizeof(X.full_inv));
       memcpy(X.fwd, fwd.m, sizeof(X.fwd));
       out.xforms.push_back(X);
+      out.xform_chain.push_back(emit_chain());
       L.xform = (int)out.xforms.size() - 1;
       if (plain_tri && share) {
         share->material = L.material;
@@ -865,6 +897,10 @@ rt_scene_desc FlatWorld::desc() const {
   d.n_materials = (int32_t)materials.size();
   d.n_patterns = (int32_t)patterns.size();
   d.n_csg = (int32_t)csg.size();
+  d.n_chain_mats = (int32_t)(chain_mats.size() / 16);
+  d.chain_mats = chain_mats.data();
+  d.xform_chain = xform_chain.data();
+  d.gate_chain = gate_chain.data();
   d.csg = csg.data();
   d.leaves = leaves.data();
   d.gates = gates.data();

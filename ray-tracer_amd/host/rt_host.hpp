@@ -97,6 +97,9 @@ struct FlatWorld {
   std::vector<rt_triangle> triangles;
   std::vector<rt_material> materials;
   std::vector<rt_pattern> patterns;
+  // transform chains of the shapes and groups that need them (see rt_scene_desc in rt_amd.h)
+  std::vector<double> chain_mats;  // 16 per matrix
+  std::vector<rt_chain_ref> xform_chain, gate_chain;
   rt_light light;
   rt_scene_desc desc() const;
 };

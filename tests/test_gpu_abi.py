@@ -31,9 +31,10 @@ class RtPattern(C.Structure):
 class RtSceneDesc(C.Structure):
     _fields_ = [("light", RtLight), ("n_leaves", C.c_int32), ("n_gates", C.c_int32), ("n_xforms", C.c_int32),
                 ("n_triangles", C.c_int32), ("n_materials", C.c_int32), ("n_patterns", C.c_int32),
-                ("n_csg", C.c_int32), ("reserved", C.c_int32), ("csg", C.c_void_p), ("leaves", C.c_void_p),
+                ("n_csg", C.c_int32), ("n_chain_mats", C.c_int32), ("csg", C.c_void_p), ("leaves", C.c_void_p),
                 ("gates", C.c_void_p), ("xforms", C.c_void_p), ("triangles", C.c_void_p),
-                ("materials", C.POINTER(RtMaterial)), ("patterns", C.POINTER(RtPattern))]
+                ("materials", C.POINTER(RtMaterial)), ("patterns", C.POINTER(RtPattern)),
+                ("chain_mats", C.c_void_p), ("xform_chain", C.c_void_p), ("gate_chain", C.c_void_p)]
 
 
 RT_PAT_BLEND = 7

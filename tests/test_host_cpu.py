@@ -142,3 +142,51 @@ def test_bvh_build_does_not_depend_on_the_thread_count(pkg, n_items):
     assert len(set(results.values())) == 1
     if n_items >= 5000:
         assert results[1][1] > n_items // 16
+
+
+def test_transform_chains_are_listed_only_where_the_product_is_inexact(pkg):
+    """A ray reaches a nested shape through one transform_inverse per level (src/shape.rs:1467-1470).
+    The flattener lists those matrices for the device when two or more differ from the identity;
+    with fewer the single product is the same ray bit for bit and no chain is emitted."""
+    class Ref(ctypes.Structure):
+        _fields_ = [("first", ctypes.c_int32), ("count", ctypes.c_int32)]
+
+    class Desc(ctypes.Structure):  # rt_scene_desc of include/rt_amd.h
+        _fields_ = [("light", ctypes.c_double * 6)] + [(n, ctypes.c_int32) for n in (
+            "n_leaves", "n_gates", "n_xforms", "n_triangles", "n_materials", "n_patterns", "n_csg", "n_chain_mats")] + [
+            (n, ctypes.c_void_p) for n in ("csg", "leaves", "gates", "xforms", "triangles", "materials", "patterns")] + [
+            ("chain_mats", ctypes.POINTER(ctypes.c_double)), ("xform_chain", ctypes.POINTER(Ref)),
+            ("gate_chain", ctypes.POINTER(Ref))]
+
+    _, host = pkg.libraries()
+    host.rth_scene_desc.restype = ctypes.POINTER(Desc)
+    host.rth_scene_desc.argtypes = [ctypes.c_void_p]
+    base = json.load(open(os.path.join(ROOT, "scenes", "example.json")))
+    move = [1, 0, 0, 2, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    grow = [2, 0, 0, 0, 0, 3, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 1]
+    turn = [0, 0, 1, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 0, 1]
+    shapes = [
+        {"ty": "sphere", "transform": move},                                                     # top level: none
+        {"ty": "group", "transform": move, "children": [{"ty": "cube"}]},                        # one matrix: none
+        {"ty": "group", "children": [{"ty": "cube", "transform": grow}]},                        # one matrix: none
+        {"ty": "group", "transform": move, "children": [                                         # gate: none
+            {"ty": "cube", "transform": grow},                                                   # two: chain
+            {"ty": "group", "transform": turn, "children": [{"ty": "sphere", "transform": grow},  # gate two, leaf three
+                                                            {"ty": "sphere"}]}]},                # two
+        {"ty": "difference", "transform": turn, "children": [{"ty": "sphere", "transform": move}, {"ty": "cube"}]},
+    ]
+    s = pkg.Scene(json.dumps(dict(base, shapes=shapes)), ROOT, device=None)
+    d = host.rth_scene_desc(s._h).contents
+    assert d.n_xforms == 8 and d.n_gates == 4
+    assert [d.xform_chain[i].count for i in range(8)] == [0, 0, 0, 2, 3, 2, 2, 0]
+    assert [d.gate_chain[i].count for i in range(4)] == [0, 0, 0, 2]
+    assert d.n_chain_mats == 2 + 3 + 2 + 2 + 2
+    inv = lambda m: np.linalg.inv(np.array(m, float).reshape(4, 4))
+    f = d.xform_chain[4].first  # the sphere three levels down: move, turn, grow, outermost first
+    got = np.array([d.chain_mats[16 * f + k] for k in range(48)]).reshape(3, 4, 4)
+    for g, want in zip(got, (inv(move), inv(turn), inv(grow))):
+        assert np.allclose(g, want, atol=1e-15)
+    # the shipped scenes, the teapot's transformed model with its identity OBJ groups included, need none
+    for name in ("example", "egg", "glass", "pattern", "teapot"):
+        t = pkg.Scene.from_file(os.path.join(ROOT, "scenes", name + ".json"), base_dir=ROOT, device=None)
+        assert host.rth_scene_desc(t._h).contents.n_chain_mats == 0, name
