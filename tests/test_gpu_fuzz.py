@@ -148,7 +148,7 @@ def compare(out, stats, want, label):
     assert abs(stats.refract - want["counts"][3]) <= max(2, want["counts"][3] * 1e-3)
 
 
-# RT_FUZZ_SEEDS=n widens the sweep (1500 seeds were run once: all equal)
+# RT_FUZZ_SEEDS, RT_FUZZ_CROWDS, RT_FUZZ_MESHES widen the sweeps (1500 / 80 / 400 seeds were run once: all equal)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_SEEDS", "60"))))
 def test_random_scene_matches_oracle(pkg, root, seed):
     text = random_scene(seed)
@@ -162,3 +162,116 @@ def test_random_scene_matches_oracle(pkg, root, seed):
     out, stats = gpu.render()
     want = cpu.render(jobs=8)
     compare(out, stats, want, "seed %d" % seed)
+
+
+def crowd_scene(seed, width=64, height=48):
+    """Hundreds of small primitives, half of them cones: deep hierarchies, and enough bounded cones for
+    the direction grid of their parallel-ray branch (more than 32) to be built and used."""
+    rng = np.random.default_rng(0xC20D + seed)
+    n = int(rng.integers(120, 420))
+    spread = float(rng.choice([6.0, 12.0]))
+    shapes = []
+    for _ in range(n):
+        ty = str(rng.choice(["bounded_cone", "capped_cone", "bounded_dn_cone", "capped_dn_cone", "sphere", "capped_cylinder",
+                             "bounded_cylinder", "cube"]))
+        s = {"ty": ty, "material": _material(rng), "transform": _mat(rng, spread, 0.15, 0.9)}
+        if rng.random() < 0.1:
+            s = {"ty": "group", "transform": _mat(rng, 1.0, 0.7, 1.3), "children": [s, _primitive(rng, spread, wild_ok=False)]}
+        shapes.append(s)
+    shapes.append({"ty": "plane", "material": _material(rng)})
+    a = rng.uniform(0, 2 * math.pi)
+    return json.dumps({
+        "canvas_width": width, "canvas_height": height, "field_of_view": float(rng.uniform(0.7, 1.3)),
+        "camera_from": [1.8 * spread * math.cos(a), float(rng.uniform(1.0, spread)), 1.8 * spread * math.sin(a)],
+        "camera_to": [0.0, spread * 0.3, 0.0], "camera_up": [0.0, 1.0, 0.0],
+        "light": {"intensity": [1.0, 1.0, 1.0], "position": [float(v) for v in rng.uniform(-spread, spread, 3) + np.array([0, 2 * spread, 0])]},
+        "shapes": shapes})
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_CROWDS", "8"))))
+def test_random_crowd_matches_oracle(pkg, root, seed):
+    text = crowd_scene(seed)
+    gpu = pkg.Scene(text, base_dir=root, device=0)
+    cpu = orc.OracleScene(text, base_dir=root)
+    out, stats = gpu.render()
+    compare(out, stats, cpu.render(jobs=8), "crowd %d" % seed)
+
+
+def mesh_scene(seed, obj_path, width=72, height=48):
+    """A random triangle soup (flat and smooth faces, polygons, OBJ groups) written as an OBJ file and
+    loaded as a model: under its own transform, inside a transformed group (so the triangles sit three
+    transform levels down and two of them are not the identity), next to a second, untransformed copy."""
+    rng = np.random.default_rng(0x0B7 + seed)
+    nv = int(rng.integers(12, 120))
+    verts = rng.uniform(-1.5, 1.5, (nv, 3))
+    normals = rng.normal(size=(nv, 3))
+    lines = ["# random soup %d" % seed]
+    lines += ["v %r %r %r" % tuple(float(c) for c in v) for v in verts]
+    smooth = rng.random() < 0.6
+    if smooth:
+        lines += ["vn %r %r %r" % tuple(float(c) for c in v) for v in normals]
+    for f in range(int(rng.integers(10, 160))):
+        if rng.random() < 0.08:
+            lines.append("g part%d" % int(rng.integers(0, 4)))
+        k = 3 if rng.random() < 0.8 else int(rng.integers(4, 6))  # polygons are fanned (src/obj.rs)
+        idx = rng.choice(nv, k, replace=False) + 1
+        lines.append("f " + " ".join(("%d//%d" % (i, i)) if smooth else str(i) for i in idx))
+    with open(obj_path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    model = {"ty": "model", "path": obj_path, "transform": _mat(rng, 1.0, 0.6, 1.4)}
+    shapes = [{"ty": "group", "transform": _mat(rng, 1.5, 0.7, 1.3), "children": [model, _primitive(rng, 2.0, wild_ok=False)]},
+              {"ty": "model", "path": obj_path},
+              {"ty": "plane", "transform": [1, 0, 0, 0, 0, 1, 0, -2.5, 0, 0, 1, 0, 0, 0, 0, 1], "material": _material(rng)}]
+    a = rng.uniform(0, 2 * math.pi)
+    return json.dumps({
+        "canvas_width": width, "canvas_height": height, "field_of_view": 1.0,
+        "camera_from": [7 * math.cos(a), float(rng.uniform(0.5, 4)), 7 * math.sin(a)], "camera_to": [0.0, 0.5, 0.0],
+        "camera_up": [0.0, 1.0, 0.0],
+        "light": {"intensity": [1.0, 1.0, 1.0], "position": [float(v) for v in rng.uniform(-6, 6, 3) + np.array([0, 9, 0])]},
+        "shapes": shapes})
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_MESHES", "12"))))
+def test_random_mesh_matches_oracle(pkg, root, seed, tmp_path):
+    text = mesh_scene(seed, str(tmp_path / "soup.obj"))
+    gpu = pkg.Scene(text, base_dir=root, device=0)
+    cpu = orc.OracleScene(text, base_dir=root)
+    assert gpu.info()["leaves"] == cpu.info()["leaves"]
+    out, stats = gpu.render()
+    compare(out, stats, cpu.render(jobs=8), "mesh %d" % seed)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_caller_rays_through_a_crowd(pkg, root, seed):
+    """The per-ray entry points on a crowd scene with rays a camera never produces: directions that are
+    not unit vectors (the cone direction grid is built for unit directions; the others take the list),
+    origins inside the crowd, axis-parallel directions.  Hit leaf and t must be identical, colours to
+    rounding, shadow answers equal."""
+    text = crowd_scene(100 + seed)
+    gpu = pkg.Scene(text, base_dir=root, device=0)
+    cpu = orc.OracleScene(text, base_dir=root)
+    rng = np.random.default_rng(seed)
+    n = 3000
+    rays = np.empty((n, 6))
+    rays[:, :3] = rng.uniform(-10, 10, (n, 3)) * np.array([1.0, 0.5, 1.0]) + np.array([0.0, 4.0, 0.0])
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[: n // 3] *= rng.uniform(0.05, 30.0, (n // 3, 1))       # not unit length
+    axis = rng.integers(0, 3, n // 10)
+    d[n // 3: n // 3 + n // 10] = np.eye(3)[axis] * rng.choice([-1.0, 1.0], (n // 10, 1))  # along an axis
+    rays[:, 3:] = d
+    t, leaf = gpu.intersect_hit(rays)
+    wt, wleaf = cpu.intersect_hit(rays)
+    assert np.array_equal(leaf, wleaf)
+    assert np.array_equal(t[wleaf >= 0], wt[wleaf >= 0])
+    rgb, leaf2, _ = gpu.color_at(rays)
+    want, wleaf2, _ = cpu.color_at(rays)
+    assert np.array_equal(leaf2, wleaf2)
+    # unbounded multipliers (a direction of length 30 reflected five times) overflow in both alike
+    fin = np.isfinite(rgb) & np.isfinite(want)
+    assert np.array_equal(rgb[~fin], want[~fin], equal_nan=True)
+    err = np.abs(np.where(fin, rgb, 0) - np.where(fin, want, 0)) / np.maximum(1.0, np.abs(np.where(fin, want, 0)))
+    print("crowd rays %d: hits %d max err %.2e" % (seed, int((wleaf >= 0).sum()), err.max()))
+    assert err.max() <= 1e-9
+    pts = rays[:, :3]
+    assert np.array_equal(gpu.is_shadowed(pts), cpu.is_shadowed(pts))
