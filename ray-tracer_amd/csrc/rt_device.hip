@@ -1169,6 +1169,9 @@ DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
+#ifndef RT_XCD_RUN
+#define RT_XCD_RUN 16  // pixel blocks (waves) per run on one XCD: 16 = one 32x32 tile; 1 = plain order
+#endif
 #ifndef RT_MIN_WAVES_SPAWN
 #define RT_MIN_WAVES_SPAWN 3
 #endif
@@ -1187,7 +1190,24 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
   // i: the thread's ray; rec: where the ray's record lives.  Camera rays and rays handed in by the
   // caller are dense (rec == i, n of them); spawned rays are found through the segment counters the
   // generation before left in queue_counts, and n only bounds the grid.
-  const uint32_t i = blockIdx.x * BLOCK + thread_in_block();
+  // Camera rays: which 8x8 pixel block a wave takes.  Workgroups are dealt round-robin over the eight
+  // XCDs (blocks b and b + 8 share one, each XCD with its own L2), so consecutive block numbers
+  // would spread the sixteen blocks of a tile over all eight L2s: every L2 would hold the nodes and
+  // triangles behind every part of the image, and every 128-byte line of the frame would leave
+  // several L2s as partial writes.  Instead the blocks that share an XCD take runs of XCD_RUN
+  // consecutive pixel blocks: one 32 x 32 tile.  Measured on the 1M-triangle mesh at 4K: 2.96 ms in
+  // plain order, 2.74 ms with runs of 16, 2.77 with 64, 3.14 with 256 (longer runs leave the XCDs
+  // unevenly loaded: the teapot frame gets 5 % slower at 64 and is unchanged at 16).
+  uint32_t wave_index = blockIdx.x;
+  if (MODE != 2) {
+    constexpr uint32_t XCD_RUN = RT_XCD_RUN, XCDS = 8;
+    const uint32_t full = gridDim.x - gridDim.x % (XCDS * XCD_RUN);  // the rest keeps its order
+    if (XCD_RUN > 1 && wave_index < full) {
+      const uint32_t xcd = wave_index % XCDS, k = wave_index / XCDS;
+      wave_index = ((k / XCD_RUN) * XCDS + xcd) * XCD_RUN + k % XCD_RUN;
+    }
+  }
+  const uint32_t i = wave_index * BLOCK + thread_in_block();
   uint32_t rec = i;
   bool active = i < n;
   if (MODE == 2 && queue_counts) active = queue_slot(queue_counts, segcap, i, rec) && active;
