@@ -190,3 +190,15 @@ def test_transform_chains_are_listed_only_where_the_product_is_inexact(pkg):
     for name in ("example", "egg", "glass", "pattern", "teapot"):
         t = pkg.Scene.from_file(os.path.join(ROOT, "scenes", name + ".json"), base_dir=ROOT, device=None)
         assert host.rth_scene_desc(t._h).contents.n_chain_mats == 0, name
+
+
+@pytest.mark.parametrize("seed", range(25))
+def test_random_scenes_flatten_like_the_oracle_tree(pkg, seed, tmp_path):
+    """The host loader and the oracle's loader read the same random JSON (nested groups, CSG pairs,
+    every primitive name, models from a generated OBJ file) into the same number of leaves."""
+    import test_gpu_fuzz as fuzz
+    for text in (fuzz.random_scene(seed), fuzz.mesh_scene(seed, str(tmp_path / "soup.obj"))):
+        s = pkg.Scene(text, ROOT, device=None)
+        ref = orc.OracleScene(text, base_dir=ROOT)
+        assert s.info()["leaves"] == ref.info()["leaves"]
+        assert (s.info()["width"], s.info()["height"]) == (ref.info()["width"], ref.info()["height"])
