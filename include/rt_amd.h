@@ -313,6 +313,12 @@ uint64_t rt_ppm_max_bytes(uint64_t width, uint64_t height);
  * index failed to list for a direction that needs them (0 = conservative) or a negative rt_status.
  * No counterpart in the reference, which scans every shape for every ray. */
 int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int* grid_n, uint64_t* entries);
+/* Diagnostic: the same index built on the host and by the kernels that build it on `device` when a
+ * scene is created, over n_bands random cones.  Returns 0 when the two are equal word for word, 1 when
+ * they differ, or a negative rt_status.  *grid_n, *entries: resolution and size; *host_seconds,
+ * *device_seconds: build times (any of the four may be null). */
+int rt_selftest_band_grid_device(int n_bands, uint64_t seed, int device, int* grid_n, uint64_t* entries,
+                                 double* host_seconds, double* device_seconds);
 
 /* Diagnostic, host only: builds the acceleration structure over n_items random boxes (70 % triangle
  * slots, 30 % quadric slots) with `threads` build threads (0 = default) and returns a hash of every

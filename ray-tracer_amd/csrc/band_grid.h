@@ -17,7 +17,18 @@ struct BandGrid {
   std::vector<uint32_t> items;  // band indices
 };
 
-// Builds the grid for bands (empty grid when there are few of them).  max_items bounds the memory.
+// Builds the grid for bands (empty grid when there are few of them).  max_items bounds the memory:
+// while the grid holds more entries the resolution is halved.
 BandGrid build_band_grid(const std::vector<ConeBand>& bands, size_t max_items);
+
+// The resolution both builders try first for n_bands cones.
+int band_grid_first_n(size_t n_bands);
+
+// The same grid built on the GPU from bands already in device memory (the current device's): same
+// cells, same entries in the same order as build_band_grid.  On success *d_start (3 n n + 1 words) and
+// *d_items (*n_items words) are hipMalloc'ed buffers the caller owns; *n_out = 0 and null buffers when
+// there are too few bands for a grid.  Returns 0 or a negative rt_status (rt_last_error() says why).
+int build_band_grid_device(const ConeBand* d_bands, size_t n_bands, size_t max_items, int* n_out, uint32_t** d_start,
+                           uint32_t** d_items, size_t* n_items);
 
 }  // namespace rt

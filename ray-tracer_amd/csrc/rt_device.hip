@@ -2248,13 +2248,34 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((rc = upload(s, b.band_prims, &s->dev.band_prims))) return rc;
   s->dev.n_bands = (int32_t)b.bands.size();
   if (getenv("RT_AMD_TIMING_NO_BANDS")) s->dev.n_bands = 0;  // timing experiment only: drops the cones' parallel-ray hits
-  {
+  if (getenv("RT_AMD_BAND_GRID_HOST")) {  // the host builder (what the device builder is checked against)
     BandGrid grid = build_band_grid(b.bands, (size_t)1 << 29);  // at most 2 GiB of entries
     s->dev.band_grid_n = grid.n;
     if ((rc = upload(s, grid.start, &s->dev.band_start))) return rc;
     if ((rc = upload(s, grid.items, &s->dev.band_items))) return rc;
     if (getenv("RT_AMD_DEBUG"))
       fprintf(stderr, "[rt_amd] band grid n=%d cells=%zu entries=%zu\n", grid.n, grid.start.size(), grid.items.size());
+  } else {
+    // built on this GPU from the bands just uploaded: milliseconds where the host builder takes seconds
+    const auto g0 = std::chrono::steady_clock::now();
+    int n = 0;
+    uint32_t *d_start = nullptr, *d_items = nullptr;
+    size_t n_items = 0;
+    if ((rc = build_band_grid_device(s->dev.bands, b.bands.size(), (size_t)1 << 29, &n, &d_start, &d_items, &n_items))) return rc;
+    s->dev.band_grid_n = n;
+    s->dev.band_start = d_start;
+    s->dev.band_items = d_items;
+    if (d_start) {
+      s->allocs.push_back(d_start);
+      s->scene_bytes += ((size_t)3 * n * n + 1) * 4;
+    }
+    if (d_items) {
+      s->allocs.push_back(d_items);
+      s->scene_bytes += n_items * 4;
+    }
+    if (getenv("RT_AMD_DEBUG"))
+      fprintf(stderr, "[rt_amd] band grid n=%d entries=%zu built on the device in %.1f ms\n", n, n_items,
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count() * 1e3);
   }
   if ((rc = upload(s, leaves, &s->dev.leaves))) return rc;
   if ((rc = upload(s, xforms, &s->dev.xforms))) return rc;
