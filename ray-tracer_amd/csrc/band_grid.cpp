@@ -35,7 +35,7 @@ void raster_band(const ConeBand& b, int n, Emit&& emit) {
 
 int band_grid_first_n(size_t n_bands) {
   int n = 32;
-  static const int n_max = getenv("RT_AMD_BAND_GRID_MAX") ? atoi(getenv("RT_AMD_BAND_GRID_MAX")) : 2048;  // experiment knob
+  static const int n_max = getenv("RT_AMD_BAND_GRID_MAX") ? atoi(getenv("RT_AMD_BAND_GRID_MAX")) : 4096;  // cells per side of a face, at most
   while (n < n_max && n < 1.7 * (double)n_bands) n *= 2;
   return n;
 }
