@@ -58,44 +58,59 @@ __device__ void walk(const FacePoly& p, double thr, int from_n, int to_n, int iu
   }
 }
 
+// Adds the lanes' counts of one wave to *total with one atomic (the 32-bit scans cannot tell a
+// wrapped sum from a small one; this 64-bit total can).
+__device__ void add_to_total(unsigned long long* total, uint32_t mine) {
+  unsigned long long v = mine;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63u) == 0 && v) atomicAdd(total, v);
+}
+
 // Step 1.  FILL = false: counts[t] = cells of the MID level band-and-face t reaches.  FILL = true:
 // lists them at offsets[t]: (band, face * mid * mid + iv * mid + iu).
 template <bool FILL>
 __global__ void __launch_bounds__(THREADS) k_mid(const ConeBand* bands, uint32_t n_bands, int mid, uint32_t* counts,
-                                                 const uint32_t* offsets, uint2* list) {
+                                                 const uint32_t* offsets, uint2* list, unsigned long long* total) {
   const uint32_t t = blockIdx.x * THREADS + threadIdx.x;
-  if (t >= 3u * n_bands) return;
-  const uint32_t band = t / 3u, face = t % 3u;
-  const ConeBand b = bands[band];
-  const FacePoly p = face_poly(b, (int)face);
-  const double thr = band_threshold(b);
+  const bool live = t < 3u * n_bands;  // no early return: the wave sums below need every lane
   uint32_t n = 0;
-  const uint32_t base = FILL ? offsets[t] : 0u;
-  if (band_cell_passes(p, thr, 1, 0, 0))
-    walk(p, thr, 1, mid, 0, 0, [&](int iu, int iv) {
-      if (FILL) list[base + n] = make_uint2(band, (face * (uint32_t)mid + (uint32_t)iv) * (uint32_t)mid + (uint32_t)iu);
-      n++;
-    });
-  if (!FILL) counts[t] = n;
+  if (live) {
+    const uint32_t band = t / 3u, face = t % 3u;
+    const ConeBand b = bands[band];
+    const FacePoly p = face_poly(b, (int)face);
+    const double thr = band_threshold(b);
+    const uint32_t base = FILL ? offsets[t] : 0u;
+    if (band_cell_passes(p, thr, 1, 0, 0))
+      walk(p, thr, 1, mid, 0, 0, [&](int iu, int iv) {
+        if (FILL) list[base + n] = make_uint2(band, (face * (uint32_t)mid + (uint32_t)iv) * (uint32_t)mid + (uint32_t)iu);
+        n++;
+      });
+    if (!FILL) counts[t] = n;
+  }
+  if (!FILL) add_to_total(total, n);
 }
 
 // Steps 2 and 3.  FILL = false: cell_count[cell]++ for every finest cell below a listed cell.
 // FILL = true: items[cursor[cell]++] = band.
 template <bool FILL>
 __global__ void __launch_bounds__(THREADS) k_fine(const ConeBand* bands, const uint2* list, uint32_t n_list, int mid, int n,
-                                                  uint32_t* cell_counter, uint32_t* items) {
+                                                  uint32_t* cell_counter, uint32_t* items, unsigned long long* total) {
   const uint32_t t = blockIdx.x * THREADS + threadIdx.x;
-  if (t >= n_list) return;
-  const uint2 e = list[t];
-  const uint32_t face = e.y / ((uint32_t)mid * (uint32_t)mid), in_face = e.y % ((uint32_t)mid * (uint32_t)mid);
-  const ConeBand b = bands[e.x];
-  const FacePoly p = face_poly(b, (int)face);
-  const double thr = band_threshold(b);
-  walk(p, thr, mid, n, (int)(in_face % (uint32_t)mid), (int)(in_face / (uint32_t)mid), [&](int iu, int iv) {
-    const size_t cell = ((size_t)face * n + iv) * n + iu;
-    const uint32_t at = atomicAdd(&cell_counter[cell], 1u);
-    if (FILL) items[at] = e.x;
-  });
+  uint32_t mine = 0;
+  if (t < n_list) {
+    const uint2 e = list[t];
+    const uint32_t face = e.y / ((uint32_t)mid * (uint32_t)mid), in_face = e.y % ((uint32_t)mid * (uint32_t)mid);
+    const ConeBand b = bands[e.x];
+    const FacePoly p = face_poly(b, (int)face);
+    const double thr = band_threshold(b);
+    walk(p, thr, mid, n, (int)(in_face % (uint32_t)mid), (int)(in_face / (uint32_t)mid), [&](int iu, int iv) {
+      const size_t cell = ((size_t)face * n + iv) * n + iu;
+      const uint32_t at = atomicAdd(&cell_counter[cell], 1u);
+      if (FILL) items[at] = e.x;
+      mine++;
+    });
+  }
+  if (!FILL) add_to_total(total, mine);
 }
 
 // Step 4: ascending band index inside every cell.
@@ -133,13 +148,18 @@ int build_band_grid_device(const ConeBand* d_bands, size_t n_bands, size_t max_i
   *d_start = *d_items = nullptr;
   *n_items = 0;
   if (n_bands <= 32) return RT_OK;  // a short list is cheaper to scan than to index
-  if (n_bands > 0x3FFFFFFFu) return rt_fail_message(RT_ERR_UNSUPPORTED, "too many cones for the direction index");
+  // (the scans below index with int; 2^27 is also the most primitives a scene can hold)
+  if (n_bands > ((size_t)1 << 27)) return rt_fail_message(RT_ERR_UNSUPPORTED, "too many cones for the direction index");
   int rc = RT_OK;
   const uint32_t nb = (uint32_t)n_bands, n_threads = 3u * nb;
   uint32_t *mid_counts = nullptr, *mid_offsets = nullptr, *counter = nullptr, *start = nullptr, *items = nullptr;
   uint2* list = nullptr;
-  for (int n = band_grid_first_n(n_bands);; n /= 2) {
-    const int mid = n < 256 ? n : 256;
+  unsigned long long* totals = nullptr;  // [0]: cells listed at the MID level, [1]: entries of the index
+  unsigned long long host_totals[2] = {0, 0};
+  int mid_cap = 256;
+  BG_TRY(hipMalloc(&totals, 16));
+  for (int n = band_grid_first_n(n_bands);;) {
+    const int mid = n < mid_cap ? n : mid_cap;
     const size_t cells = (size_t)3 * n * n;
     uint32_t last[2] = {0, 0};
     uint32_t n_list = 0, total = 0;
@@ -147,14 +167,22 @@ int build_band_grid_device(const ConeBand* d_bands, size_t n_bands, size_t max_i
     BG_TRY(hipMalloc(&mid_counts, ((size_t)n_threads + 1) * 4));
     BG_TRY(hipMalloc(&mid_offsets, ((size_t)n_threads + 1) * 4));
     BG_TRY(hipMemset(mid_counts, 0, ((size_t)n_threads + 1) * 4));
+    BG_TRY(hipMemset(totals, 0, 16));
     hipLaunchKernelGGL(k_mid<false>, dim3((n_threads + THREADS - 1) / THREADS), dim3(THREADS), 0, 0, d_bands, nb, mid,
-                       mid_counts, (const uint32_t*)nullptr, (uint2*)nullptr);
+                       mid_counts, (const uint32_t*)nullptr, (uint2*)nullptr, totals);
     BG_TRY(hipGetLastError());
+    BG_TRY(hipMemcpy(host_totals, totals, 8, hipMemcpyDeviceToHost));
+    if (host_totals[0] > 0x7FFFFFFFull && mid_cap > 1) {  // too many cells for the 32-bit list: a coarser MID level
+      (void)hipFree(mid_counts); (void)hipFree(mid_offsets);
+      mid_counts = mid_offsets = nullptr;
+      mid_cap /= 2;
+      continue;
+    }
     BG_TRY((hipError_t)exclusive_sum(mid_counts, mid_offsets, (size_t)n_threads + 1));
     BG_TRY(hipMemcpy(&n_list, mid_offsets + n_threads, 4, hipMemcpyDeviceToHost));
     BG_TRY(hipMalloc(&list, ((size_t)n_list + 1) * sizeof(uint2)));
     hipLaunchKernelGGL(k_mid<true>, dim3((n_threads + THREADS - 1) / THREADS), dim3(THREADS), 0, 0, d_bands, nb, mid,
-                       mid_counts, (const uint32_t*)mid_offsets, list);
+                       mid_counts, (const uint32_t*)mid_offsets, list, totals);
     BG_TRY(hipGetLastError());
     // step 2
     BG_TRY(hipMalloc(&counter, (cells + 1) * 4));
@@ -162,23 +190,29 @@ int build_band_grid_device(const ConeBand* d_bands, size_t n_bands, size_t max_i
     BG_TRY(hipMemset(counter, 0, (cells + 1) * 4));
     if (n_list)
       hipLaunchKernelGGL(k_fine<false>, dim3((n_list + THREADS - 1) / THREADS), dim3(THREADS), 0, 0, d_bands,
-                         (const uint2*)list, n_list, mid, n, counter, (uint32_t*)nullptr);
+                         (const uint2*)list, n_list, mid, n, counter, (uint32_t*)nullptr, totals + 1);
     BG_TRY(hipGetLastError());
-    BG_TRY((hipError_t)exclusive_sum(counter, start, cells + 1));
-    BG_TRY(hipMemcpy(last, start + cells, 4, hipMemcpyDeviceToHost));
-    total = last[0];
-    if ((size_t)total > max_items && n > 32) {  // coarser cells: fewer entries per band
+    BG_TRY(hipMemcpy(host_totals, totals, 16, hipMemcpyDeviceToHost));
+    if (host_totals[1] > (unsigned long long)max_items && n > 32) {  // coarser cells: fewer entries per band
       (void)hipFree(mid_counts); (void)hipFree(mid_offsets); (void)hipFree(list); (void)hipFree(counter); (void)hipFree(start);
       mid_counts = mid_offsets = counter = start = nullptr;
       list = nullptr;
+      n /= 2;
       continue;
     }
+    if (host_totals[1] > 0xFFFFFFFFull) {
+      rc = rt_fail_message(RT_ERR_UNSUPPORTED, "the cone direction index would hold more than 2^32 entries");
+      goto done;
+    }
+    BG_TRY((hipError_t)exclusive_sum(counter, start, cells + 1));
+    BG_TRY(hipMemcpy(last, start + cells, 4, hipMemcpyDeviceToHost));
+    total = last[0];
     // steps 3 and 4: the offsets double as the fill cursors of a copy
     BG_TRY(hipMalloc(&items, ((size_t)total + 1) * 4));
     BG_TRY(hipMemcpy(counter, start, (cells + 1) * 4, hipMemcpyDeviceToDevice));
     if (n_list)
       hipLaunchKernelGGL(k_fine<true>, dim3((n_list + THREADS - 1) / THREADS), dim3(THREADS), 0, 0, d_bands,
-                         (const uint2*)list, n_list, mid, n, counter, items);
+                         (const uint2*)list, n_list, mid, n, counter, items, totals + 1);
     BG_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_sort_cells, dim3((uint32_t)((cells + THREADS - 1) / THREADS)), dim3(THREADS), 0, 0,
                        (const uint32_t*)start, (uint32_t)cells, items);
@@ -192,6 +226,7 @@ int build_band_grid_device(const ConeBand* d_bands, size_t n_bands, size_t max_i
     break;
   }
 done:
+  if (totals) (void)hipFree(totals);
   if (mid_counts) (void)hipFree(mid_counts);
   if (mid_offsets) (void)hipFree(mid_offsets);
   if (list) (void)hipFree(list);
