@@ -2261,7 +2261,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     int n = 0;
     uint32_t *d_start = nullptr, *d_items = nullptr;
     size_t n_items = 0;
-    if ((rc = build_band_grid_device(s->dev.bands, b.bands.size(), (size_t)1 << 29, &n, &d_start, &d_items, &n_items))) return rc;
+    if ((rc = build_band_grid_device(s->dev.bands, b.bands.size(), (size_t)1 << 30, &n, &d_start, &d_items, &n_items))) return rc;
     s->dev.band_grid_n = n;
     s->dev.band_start = d_start;
     s->dev.band_items = d_items;
