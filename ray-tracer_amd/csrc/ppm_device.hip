@@ -305,65 +305,101 @@ __global__ void __launch_bounds__(CHUNK* WAVES_PER_BLOCK)
 
 extern "C" uint64_t rt_ppm_max_bytes(uint64_t width, uint64_t height) { return 48 + 12 * width * height + 1; }
 
-extern "C" int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
-                             uint64_t capacity, uint64_t* length) {
+namespace {
+
+// Workspace of one encode: tables, byte counts, columns, offsets, the length (about 2.2 bytes per pixel).
+struct PpmLayout {
+  uint64_t n_chunks, n_spans;
+  uint64_t maps, span_maps, chunk_bytes, span_bytes, chunk_col, span_col, chunk_off, span_off, length, bytes;
+};
+constexpr uint64_t up256(uint64_t v) { return (v + 255) & ~255ull; }
+constexpr PpmLayout ppm_layout(uint64_t n) {
+  PpmLayout L{};
+  L.n_chunks = (n + CHUNK - 1) / CHUNK;
+  L.n_spans = (L.n_chunks + SPAN - 1) / SPAN;
+  L.maps = 0;
+  L.span_maps = L.maps + up256(L.n_chunks * STATES);
+  L.chunk_bytes = L.span_maps + up256(L.n_spans * STATES);
+  L.span_bytes = L.chunk_bytes + up256(L.n_chunks * 4);
+  L.chunk_col = L.span_bytes + up256(L.n_spans * 8);
+  L.span_col = L.chunk_col + up256(L.n_chunks);
+  L.chunk_off = L.span_col + up256(L.n_spans);
+  L.span_off = L.chunk_off + up256(L.n_chunks * 8);
+  L.length = L.span_off + up256(L.n_spans * 8);
+  L.bytes = L.length + 256;
+  return L;
+}
+
+int ppm_check_arguments(const char* who, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
+                        uint64_t capacity, uint64_t* length) {
+  const std::string name(who);
   if (!out_dev || !length || (!rgb8_dev && width * height > 0))
-    return rt_fail_message(RT_ERR_INVALID, "rt_ppm_encode: null argument");
+    return rt_fail_message(RT_ERR_INVALID, (name + ": null argument").c_str());
   if (width > 0xFFFFFFFFull || height > 0xFFFFFFFFull || (height && width > (1ull << 40) / height))
-    return rt_fail_message(RT_ERR_INVALID, "rt_ppm_encode: image too large");
+    return rt_fail_message(RT_ERR_INVALID, (name + ": image too large").c_str());
   if (capacity < rt_ppm_max_bytes(width, height))
-    return rt_fail_message(RT_ERR_INVALID, "rt_ppm_encode: output buffer smaller than rt_ppm_max_bytes(width, height)");
+    return rt_fail_message(RT_ERR_INVALID, (name + ": output buffer smaller than rt_ppm_max_bytes(width, height)").c_str());
+  return RT_OK;
+}
+
+// The five kernels on `stream` over the workspace at ws (device memory of the current device, at least
+// ppm_layout(width * height).bytes, contents irrelevant: every word the kernels read was written by an earlier
+// kernel of the same call), then the length of the file.  Blocking.  Allocates nothing.
+int ppm_run(char* ws, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev, uint64_t* length,
+            hipStream_t stream) {
   int rc = RT_OK;
   const uint64_t n = width * height;
-  const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK, n_spans = (n_chunks + SPAN - 1) / SPAN;
+  const PpmLayout L = ppm_layout(n);
+  const uint64_t n_chunks = L.n_chunks, n_spans = L.n_spans;
   PpmHeader header;
   memset(&header, 0, sizeof header);
   header.length = (uint32_t)snprintf(header.text, sizeof header.text, "P3\n%llu %llu\n255\n", (unsigned long long)width,
                                      (unsigned long long)height);  // src/canvas.rs:52-54
-  // workspace: tables, byte counts, columns, offsets, the length
-  auto up = [](uint64_t v) { return (v + 255) & ~255ull; };
-  const uint64_t o_maps = 0, o_span_maps = o_maps + up(n_chunks * STATES), o_chunk_bytes = o_span_maps + up(n_spans * STATES),
-                 o_span_bytes = o_chunk_bytes + up(n_chunks * 4), o_chunk_col = o_span_bytes + up(n_spans * 8),
-                 o_span_col = o_chunk_col + up(n_chunks), o_chunk_off = o_span_col + up(n_spans),
-                 o_span_off = o_chunk_off + up(n_chunks * 8), o_length = o_span_off + up(n_spans * 8),
-                 bytes = o_length + 256;
+  unsigned long long host_length = 0;
+  uint8_t* maps = (uint8_t*)(ws + L.maps);
+  uint8_t* span_maps = (uint8_t*)(ws + L.span_maps);
+  uint32_t* chunk_bytes = (uint32_t*)(ws + L.chunk_bytes);
+  unsigned long long* span_bytes = (unsigned long long*)(ws + L.span_bytes);
+  uint8_t* chunk_col = (uint8_t*)(ws + L.chunk_col);
+  uint8_t* span_col = (uint8_t*)(ws + L.span_col);
+  unsigned long long* chunk_off = (unsigned long long*)(ws + L.chunk_off);
+  unsigned long long* span_off = (unsigned long long*)(ws + L.span_off);
+  unsigned long long* d_length = (unsigned long long*)(ws + L.length);
+  const dim3 block(CHUNK * WAVES_PER_BLOCK);
+  const dim3 chunk_grid((unsigned)((n_chunks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+  const dim3 span_grid((unsigned)((n_spans + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+  if (n_chunks) {
+    hipLaunchKernelGGL(k_ppm_chunk_maps, chunk_grid, block, 0, stream, rgb8_dev, n, n_chunks, maps, chunk_bytes);
+    hipLaunchKernelGGL(k_ppm_span_maps, span_grid, block, 0, stream, maps, chunk_bytes, n_chunks, n_spans, span_maps,
+                       span_bytes);
+  }
+  hipLaunchKernelGGL(k_ppm_walk_spans, dim3(1), dim3(64), 0, stream, span_maps, span_bytes, n_spans, header, span_col,
+                     span_off, out_dev, d_length);
+  if (n_chunks) {
+    hipLaunchKernelGGL(k_ppm_walk_chunks, span_grid, block, 0, stream, maps, chunk_bytes, n_chunks, n_spans, span_col,
+                       span_off, chunk_col, chunk_off);
+    hipLaunchKernelGGL(k_ppm_emit, chunk_grid, block, 0, stream, rgb8_dev, n, n_chunks, chunk_col, chunk_off, out_dev);
+  }
+  PPM_TRY(hipGetLastError());
+  PPM_TRY(hipMemcpyAsync(&host_length, d_length, sizeof host_length, hipMemcpyDeviceToHost, stream));
+  PPM_TRY(hipStreamSynchronize(stream));
+  *length = host_length;
+done:
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
+                             uint64_t capacity, uint64_t* length) {
+  int rc = ppm_check_arguments("rt_ppm_encode", rgb8_dev, width, height, out_dev, capacity, length);
+  if (rc != RT_OK) return rc;
   char* ws = nullptr;
   int previous = -1;
-  hipStream_t stream = nullptr;
-  unsigned long long host_length = 0;
   PPM_TRY(hipGetDevice(&previous));
   PPM_TRY(hipSetDevice(device));
-  PPM_TRY(hipMalloc((void**)&ws, bytes));
-  {
-    uint8_t* maps = (uint8_t*)(ws + o_maps);
-    uint8_t* span_maps = (uint8_t*)(ws + o_span_maps);
-    uint32_t* chunk_bytes = (uint32_t*)(ws + o_chunk_bytes);
-    unsigned long long* span_bytes = (unsigned long long*)(ws + o_span_bytes);
-    uint8_t* chunk_col = (uint8_t*)(ws + o_chunk_col);
-    uint8_t* span_col = (uint8_t*)(ws + o_span_col);
-    unsigned long long* chunk_off = (unsigned long long*)(ws + o_chunk_off);
-    unsigned long long* span_off = (unsigned long long*)(ws + o_span_off);
-    unsigned long long* d_length = (unsigned long long*)(ws + o_length);
-    const dim3 block(CHUNK * WAVES_PER_BLOCK);
-    const dim3 chunk_grid((unsigned)((n_chunks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
-    const dim3 span_grid((unsigned)((n_spans + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
-    if (n_chunks) {
-      hipLaunchKernelGGL(k_ppm_chunk_maps, chunk_grid, block, 0, stream, rgb8_dev, n, n_chunks, maps, chunk_bytes);
-      hipLaunchKernelGGL(k_ppm_span_maps, span_grid, block, 0, stream, maps, chunk_bytes, n_chunks, n_spans, span_maps,
-                         span_bytes);
-    }
-    hipLaunchKernelGGL(k_ppm_walk_spans, dim3(1), dim3(64), 0, stream, span_maps, span_bytes, n_spans, header, span_col,
-                       span_off, out_dev, d_length);
-    if (n_chunks) {
-      hipLaunchKernelGGL(k_ppm_walk_chunks, span_grid, block, 0, stream, maps, chunk_bytes, n_chunks, n_spans, span_col,
-                         span_off, chunk_col, chunk_off);
-      hipLaunchKernelGGL(k_ppm_emit, chunk_grid, block, 0, stream, rgb8_dev, n, n_chunks, chunk_col, chunk_off, out_dev);
-    }
-    PPM_TRY(hipGetLastError());
-    PPM_TRY(hipMemcpyAsync(&host_length, d_length, sizeof host_length, hipMemcpyDeviceToHost, stream));
-    PPM_TRY(hipStreamSynchronize(stream));
-    *length = host_length;
-  }
+  PPM_TRY(hipMalloc((void**)&ws, ppm_layout(width * height).bytes));
+  rc = ppm_run(ws, rgb8_dev, width, height, out_dev, length, nullptr);
 done:
   if (ws) (void)hipFree(ws);
   if (previous >= 0) (void)hipSetDevice(previous);
