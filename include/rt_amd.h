@@ -304,6 +304,16 @@ int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t 
  * rt_host_alloc move fastest).  When capacity is too small, *length still receives the size needed. */
 int rt_ppm_encode_host(int device, const uint8_t* rgb8_host, uint64_t width, uint64_t height, char* out_host,
                        uint64_t capacity, uint64_t* length);
+/* rt_ppm_encode for callers that cannot allocate device memory (code under HIP graph capture, serving
+ * loops and harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
+ * result byte for byte, but the workspace is a fixed array in the library's device image (about 18.4 MB
+ * on every GPU the library runs on, held until the process ends) instead of a hipMalloc per call, and the
+ * call makes no allocation of its own.  Frames of more than rt_ppm_static_max_pixels() pixels (one
+ * 3840x2160 frame) are refused with RT_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU race; calls on different GPUs do not. */
+int rt_ppm_encode_static(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
+                         uint64_t capacity, uint64_t* length);
+uint64_t rt_ppm_static_max_pixels(void);
 /* Upper bound of the file size: 12 bytes per pixel, the header, the final newline. */
 uint64_t rt_ppm_max_bytes(uint64_t width, uint64_t height);
 

@@ -100,6 +100,8 @@ def libraries():
     amd.rt_is_shadowed.argtypes = [vp, u64, vp, vp]
     amd.rt_ppm_encode.argtypes = [i32, vp, u64, u64, vp, u64, C.POINTER(u64)]
     amd.rt_ppm_encode_host.argtypes = [i32, vp, u64, u64, vp, u64, C.POINTER(u64)]
+    amd.rt_ppm_encode_static.argtypes = [i32, vp, u64, u64, vp, u64, C.POINTER(u64)]
+    amd.rt_ppm_static_max_pixels.restype = u64
     amd.rt_ppm_max_bytes.argtypes = [u64, u64]
     amd.rt_ppm_max_bytes.restype = u64
     host.rth_last_error.restype = C.c_char_p
@@ -156,12 +158,14 @@ def ppm_max_bytes(width, height):
     return int(amd.rt_ppm_max_bytes(width, height))
 
 
-def ppm_encode_device(rgb8_ptr, width, height, out_ptr, capacity, device=0):
+def ppm_encode_device(rgb8_ptr, width, height, out_ptr, capacity, device=0, static=False):
     """Canvas::save's text (src/canvas.rs:47-94) written on the GPU: rgb8_ptr and out_ptr are device
-    addresses.  Returns the length of the file in out_ptr."""
+    addresses.  Returns the length of the file in out_ptr.  static=True: rt_ppm_encode_static, which
+    works in the library's fixed workspace and allocates nothing."""
     amd, _ = libraries()
     n = C.c_uint64()
-    rc = amd.rt_ppm_encode(device, rgb8_ptr, width, height, out_ptr, capacity, C.byref(n))
+    fn = amd.rt_ppm_encode_static if static else amd.rt_ppm_encode
+    rc = fn(device, rgb8_ptr, width, height, out_ptr, capacity, C.byref(n))
     if rc != 0:
         raise RtError(rc, amd.rt_last_error().decode())
     return int(n.value)

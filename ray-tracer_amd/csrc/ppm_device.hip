@@ -19,6 +19,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/rt_amd.h"
@@ -402,6 +403,61 @@ extern "C" int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width
   rc = ppm_run(ws, rgb8_dev, width, height, out_dev, length, nullptr);
 done:
   if (ws) (void)hipFree(ws);
+  if (previous >= 0) (void)hipSetDevice(previous);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// The same encoder for callers that cannot allocate (code under HIP graph capture, serving loops that
+// forbid hipMalloc): the workspace is a fixed array in the library's device image, one copy per GPU.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr uint64_t PPM_STATIC_MAX_PIXELS = 3840ull * 2160ull;  // one 4K frame
+constexpr uint64_t PPM_STATIC_BYTES = ppm_layout(PPM_STATIC_MAX_PIXELS).bytes;  // about 18.4 MB per GPU
+}  // namespace
+// File scope: every GPU the library runs on holds its own copy at its own address until the process ends.
+// In host code this name is only a handle for hipGetSymbolAddress; it is never passed to a kernel.
+static __device__ __align__(256) unsigned char scratch[PPM_STATIC_BYTES];
+
+namespace {
+constexpr int PPM_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+char* g_scratch_ptr[PPM_MAX_DEVICES] = {nullptr};  // device address of `scratch` on each GPU, once looked up
+
+// The address of this device's copy of the array.  The device must be current.
+int scratch_on_current_device(int device, char** out) {
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p)
+      return rt_fail_message(RT_ERR_DEVICE, (std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e)).c_str());
+    g_scratch_ptr[device] = (char*)p;
+  }
+  *out = g_scratch_ptr[device];
+  return RT_OK;
+}
+}  // namespace
+
+extern "C" uint64_t rt_ppm_static_max_pixels(void) { return PPM_STATIC_MAX_PIXELS; }
+
+extern "C" int rt_ppm_encode_static(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
+                                    uint64_t capacity, uint64_t* length) {
+  int rc = ppm_check_arguments("rt_ppm_encode_static", rgb8_dev, width, height, out_dev, capacity, length);
+  if (rc != RT_OK) return rc;
+  if (width * height > PPM_STATIC_MAX_PIXELS)
+    return rt_fail_message(RT_ERR_UNSUPPORTED, ("rt_ppm_encode_static: " + std::to_string(width * height) + " pixels exceed the fixed workspace of " +
+                                                std::to_string(PPM_STATIC_MAX_PIXELS) + " (one 3840x2160 frame); use rt_ppm_encode").c_str());
+  if (device < 0 || device >= PPM_MAX_DEVICES) return rt_fail_message(RT_ERR_INVALID, "rt_ppm_encode_static: device out of range");
+  static_assert(ppm_layout(PPM_STATIC_MAX_PIXELS).bytes <= sizeof(scratch), "the fixed workspace holds the largest frame");
+  int previous = -1;
+  char* ws = nullptr;
+  PPM_TRY(hipGetDevice(&previous));
+  PPM_TRY(hipSetDevice(device));
+  rc = scratch_on_current_device(device, &ws);
+  // nothing in the workspace has to start at zero: every word a kernel reads was written earlier in the same call
+  if (rc == RT_OK) rc = ppm_run(ws, rgb8_dev, width, height, out_dev, length, nullptr);
+done:
   if (previous >= 0) (void)hipSetDevice(previous);
   return rc;
 }
