@@ -227,7 +227,7 @@ int rt_scene_footprint(const rt_scene* scene, uint64_t* scene_bytes, double* bui
  * With RT_FLAG_COMPACT (rgb8 only) the buffer holds only the part's own tiles, 3072 bytes per tile
  * in the order the part owns them (row-major over tiles), and inside a tile sixteen 8x8 pixel
  * blocks (block b at columns 8 (b % 4), rows 8 (b / 4)), each row-major; pixels of a tile that
- * fall outside the image are left unwritten.  This is the unit a multi-GPU host gathers: one
+ * fall outside the image are written as zeros.  This is the unit a multi-GPU host gathers: one
  * contiguous buffer per GPU (the reference gathers per pixel through a channel,
  * src/parallel.rs:44-49). */
 int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, uint32_t flags,
@@ -239,8 +239,12 @@ int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, u
  * needs the host between generations, so there the flag is ignored and the call blocks as usual.
  * rt_scene_wait blocks until every enqueued frame is complete and returns the sums of their ray
  * counts, kernel time and kernel launches since the previous wait (render_ms is not filled).
- * Other entry points run on the same stream and are therefore ordered after frames in flight.  The reference renders one frame per
- * process (src/main.rs:71); this pair has no counterpart there. */
+ * Asynchronous frames alternate between two streams of the scene.  rt_download / rt_download_2d without
+ * an after_stream wait for both; every blocking entry point of the scene first collects the frames in
+ * flight.  Work a caller enqueues on streams of its own (and rt_ppm_encode, which runs on the null
+ * stream) is not ordered against frames in flight: call rt_scene_wait first, or order the stream after
+ * rt_scene_stream.  The reference renders one frame per process (src/main.rs:71); this pair has no
+ * counterpart there. */
 int rt_scene_wait(rt_scene* scene, rt_stats* total);
 
 /* The HIP stream (hipStream_t) the most recent frame was enqueued on, so that a caller can order
@@ -249,8 +253,9 @@ int rt_scene_wait(rt_scene* scene, rt_stats* total);
 int rt_scene_stream(rt_scene* scene, void** hip_stream);
 
 /* Copies `bytes` from device memory to pinned (page-locked) host memory on the scene's copy
- * stream (a DMA transfer that runs beside the next frame's kernel).  The copy is enqueued; it starts after everything enqueued so far on after_stream (a hipStream_t; NULL = the
- * scene's render stream) and is complete after rt_scene_wait or after the copy stream
+ * stream (a DMA transfer that runs beside the next frame's kernel).  The copy is enqueued; it starts
+ * after everything enqueued so far on after_stream (a hipStream_t; NULL = both render streams of the
+ * scene) and is complete after rt_scene_wait or after the copy stream
  * (rt_scene_copy_stream) has drained.  The caller keeps src_dev and dst_host untouched until then.
  * Replaces the per-pixel channel receive of the reference's canvas (src/parallel.rs:196-200). */
 int rt_download(rt_scene* scene, const void* src_dev, void* dst_host, uint64_t bytes, void* after_stream);

@@ -33,9 +33,24 @@ void raster_band(const ConeBand& b, int n, Emit&& emit) {
 
 }  // namespace
 
+// Cells per side of a face: a power of two in [32, 8192].  The ceiling is what the device builder's
+// walk() can hold: its stack entries keep du, dv in 14 bits each (8192 / 1 cells below a start cell at
+// most) and the level in 4 bits, its private stack of 40 entries covers 13 levels (3 per level + 1), and
+// the scans index 3 n^2 + 1 cells with an int.
+constexpr int BAND_GRID_MIN = 32, BAND_GRID_CEILING = 8192;
+static_assert(3ll * BAND_GRID_CEILING * BAND_GRID_CEILING + 1 < 0x7FFFFFFFll, "cell count must fit an int");
+static_assert(BAND_GRID_CEILING <= (1 << 14) / 2, "walk() packs cell offsets into 14 bits");
+
 int band_grid_first_n(size_t n_bands) {
-  int n = 32;
-  static const int n_max = getenv("RT_AMD_BAND_GRID_MAX") ? atoi(getenv("RT_AMD_BAND_GRID_MAX")) : 4096;  // cells per side of a face, at most
+  static const int n_max = [] {
+    int v = 4096;
+    if (const char* e = getenv("RT_AMD_BAND_GRID_MAX")) v = atoi(e);
+    v = std::max(BAND_GRID_MIN, std::min(BAND_GRID_CEILING, v));
+    int p = BAND_GRID_MIN;
+    while (p * 2 <= v) p *= 2;  // rounded down to a power of two
+    return p;
+  }();
+  int n = BAND_GRID_MIN;
   while (n < n_max && n < 1.7 * (double)n_bands) n *= 2;
   return n;
 }

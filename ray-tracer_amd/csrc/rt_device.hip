@@ -29,6 +29,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +44,42 @@
 #include "rt_types.h"
 
 using namespace rt;
+
+// The layout of every structure that crosses the C ABI, as a binding in another language has to
+// declare it (`#[repr(C)]` in the reference's Rust): sizes and field offsets in bytes.
+#define RT_ABI_FIELD(T, f, off) static_assert(offsetof(T, f) == (off), #T "." #f " moved: the C ABI changed")
+#define RT_ABI_SIZE(T, n) static_assert(sizeof(T) == (n), #T " changed size: the C ABI changed")
+RT_ABI_SIZE(rt_xform, 384); RT_ABI_FIELD(rt_xform, ray_inv, 0); RT_ABI_FIELD(rt_xform, full_inv, 128); RT_ABI_FIELD(rt_xform, fwd, 256);
+RT_ABI_SIZE(rt_triangle, 168); RT_ABI_FIELD(rt_triangle, p1, 0); RT_ABI_FIELD(rt_triangle, e1, 24); RT_ABI_FIELD(rt_triangle, e2, 48);
+RT_ABI_FIELD(rt_triangle, normal, 72); RT_ABI_FIELD(rt_triangle, n1, 96); RT_ABI_FIELD(rt_triangle, n2, 120); RT_ABI_FIELD(rt_triangle, n3, 144);
+RT_ABI_SIZE(rt_leaf, 72); RT_ABI_FIELD(rt_leaf, type, 0); RT_ABI_FIELD(rt_leaf, closed, 4); RT_ABI_FIELD(rt_leaf, material, 8);
+RT_ABI_FIELD(rt_leaf, xform, 12); RT_ABI_FIELD(rt_leaf, gate, 16); RT_ABI_FIELD(rt_leaf, tri, 20); RT_ABI_FIELD(rt_leaf, csg, 24);
+RT_ABI_FIELD(rt_leaf, csg_left, 28); RT_ABI_FIELD(rt_leaf, minimum, 32); RT_ABI_FIELD(rt_leaf, maximum, 40); RT_ABI_FIELD(rt_leaf, plane_normal, 48);
+RT_ABI_SIZE(rt_gate, 184); RT_ABI_FIELD(rt_gate, parent, 0); RT_ABI_FIELD(rt_gate, csg, 4); RT_ABI_FIELD(rt_gate, to_local, 8);
+RT_ABI_FIELD(rt_gate, bmin, 136); RT_ABI_FIELD(rt_gate, bmax, 160);
+RT_ABI_SIZE(rt_csg, 24); RT_ABI_FIELD(rt_csg, op, 0); RT_ABI_FIELD(rt_csg, parent, 4); RT_ABI_FIELD(rt_csg, gate, 8);
+RT_ABI_FIELD(rt_csg, first_leaf, 12); RT_ABI_FIELD(rt_csg, n_leaves, 16); RT_ABI_FIELD(rt_csg, reserved, 20);
+RT_ABI_SIZE(rt_material, 88); RT_ABI_FIELD(rt_material, color, 0); RT_ABI_FIELD(rt_material, ambient, 24); RT_ABI_FIELD(rt_material, diffuse, 32);
+RT_ABI_FIELD(rt_material, specular, 40); RT_ABI_FIELD(rt_material, shininess, 48); RT_ABI_FIELD(rt_material, reflective, 56);
+RT_ABI_FIELD(rt_material, refractive_index, 64); RT_ABI_FIELD(rt_material, transparency, 72); RT_ABI_FIELD(rt_material, pattern, 80);
+RT_ABI_SIZE(rt_pattern, 192); RT_ABI_FIELD(rt_pattern, type, 0); RT_ABI_FIELD(rt_pattern, first, 4); RT_ABI_FIELD(rt_pattern, second, 8);
+RT_ABI_FIELD(rt_pattern, inv, 16); RT_ABI_FIELD(rt_pattern, a, 144); RT_ABI_FIELD(rt_pattern, b, 168);
+RT_ABI_SIZE(rt_light, 48); RT_ABI_FIELD(rt_light, intensity, 0); RT_ABI_FIELD(rt_light, position, 24);
+RT_ABI_SIZE(rt_camera, 160); RT_ABI_FIELD(rt_camera, hsize, 0); RT_ABI_FIELD(rt_camera, vsize, 4); RT_ABI_FIELD(rt_camera, half_width, 8);
+RT_ABI_FIELD(rt_camera, half_height, 16); RT_ABI_FIELD(rt_camera, pixel_size, 24); RT_ABI_FIELD(rt_camera, inv, 32);
+RT_ABI_SIZE(rt_chain_ref, 8); RT_ABI_FIELD(rt_chain_ref, first, 0); RT_ABI_FIELD(rt_chain_ref, count, 4);
+RT_ABI_SIZE(rt_scene_desc, 160); RT_ABI_FIELD(rt_scene_desc, light, 0); RT_ABI_FIELD(rt_scene_desc, n_leaves, 48);
+RT_ABI_FIELD(rt_scene_desc, n_gates, 52); RT_ABI_FIELD(rt_scene_desc, n_xforms, 56); RT_ABI_FIELD(rt_scene_desc, n_triangles, 60);
+RT_ABI_FIELD(rt_scene_desc, n_materials, 64); RT_ABI_FIELD(rt_scene_desc, n_patterns, 68); RT_ABI_FIELD(rt_scene_desc, n_csg, 72);
+RT_ABI_FIELD(rt_scene_desc, n_chain_mats, 76); RT_ABI_FIELD(rt_scene_desc, csg, 80); RT_ABI_FIELD(rt_scene_desc, leaves, 88);
+RT_ABI_FIELD(rt_scene_desc, gates, 96); RT_ABI_FIELD(rt_scene_desc, xforms, 104); RT_ABI_FIELD(rt_scene_desc, triangles, 112);
+RT_ABI_FIELD(rt_scene_desc, materials, 120); RT_ABI_FIELD(rt_scene_desc, patterns, 128); RT_ABI_FIELD(rt_scene_desc, chain_mats, 136);
+RT_ABI_FIELD(rt_scene_desc, xform_chain, 144); RT_ABI_FIELD(rt_scene_desc, gate_chain, 152);
+RT_ABI_SIZE(rt_stats, 128); RT_ABI_FIELD(rt_stats, primary, 0); RT_ABI_FIELD(rt_stats, render_ms, 32); RT_ABI_FIELD(rt_stats, kernel_ms, 40);
+RT_ABI_FIELD(rt_stats, kernel_launches, 48); RT_ABI_FIELD(rt_stats, generations, 56); RT_ABI_FIELD(rt_stats, node_visits, 64);
+RT_ABI_FIELD(rt_stats, shadow_node_visits, 96);
+#undef RT_ABI_FIELD
+#undef RT_ABI_SIZE
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -1591,7 +1628,7 @@ struct rt_scene {
   hipStream_t frame_stream = nullptr;  // asynchronous frames alternate between stream and frame_stream
   hipStream_t last_stream = nullptr;   // where the most recent frame was enqueued
   hipStream_t copy_stream = nullptr;   // rt_download
-  hipEvent_t copy_order = nullptr;
+  hipEvent_t copy_order = nullptr, copy_order2 = nullptr;
   SceneDev dev{};
   std::vector<void*> allocs;
   uint64_t scene_bytes = 0;
@@ -1985,7 +2022,10 @@ extern "C" int rt_device_count(void) {
 extern "C" void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  // frames may still run on either render stream and copies on the copy stream: drain all three
+  // before any of the memory they use is released
+  for (hipStream_t st : {s->stream, s->frame_stream, s->copy_stream})
+    if (st) (void)hipStreamSynchronize(st);
   for (void* p : s->allocs) (void)hipFree(p);
   for (GenBuf& g : s->gens)
     if (g.slab) (void)hipFree(g.slab);
@@ -2008,6 +2048,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     (void)hipStreamDestroy(s->copy_stream);
   }
   if (s->copy_order) (void)hipEventDestroy(s->copy_order);
+  if (s->copy_order2) (void)hipEventDestroy(s->copy_order2);
   if (s->frame_stream) {
     (void)hipStreamSynchronize(s->frame_stream);
     (void)hipStreamDestroy(s->frame_stream);
@@ -2021,6 +2062,9 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if (d->n_leaves < 0 || d->n_gates < 0 || d->n_xforms < 0 || d->n_triangles < 0 || d->n_materials < 0 ||
       d->n_patterns < 0)
     return fail(RT_ERR_INVALID, "negative count in scene description");
+  if ((d->n_leaves > 0 && !d->leaves) || (d->n_gates > 0 && !d->gates) || (d->n_xforms > 0 && !d->xforms) ||
+      (d->n_triangles > 0 && !d->triangles) || (d->n_materials > 0 && !d->materials) || (d->n_patterns > 0 && !d->patterns))
+    return fail(RT_ERR_INVALID, "null array with a positive count in scene description");
   for (int i = 0; i < d->n_xforms; i++) {
     if (!affine(d->xforms[i].ray_inv) || !affine(d->xforms[i].full_inv) || !affine(d->xforms[i].fwd))
       return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) shape transform: last row must be 0 0 0 1");
@@ -2057,8 +2101,18 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
         return fail(RT_ERR_INVALID, "CSG leaf range not inside its parent's");
     }
   }
-  for (int i = 0; i < d->n_gates; i++)
-    if (d->gates[i].csg < -1 || d->gates[i].csg >= d->n_csg) return fail(RT_ERR_INVALID, "gate CSG index out of range");
+  for (int i = 0; i < d->n_gates; i++) {
+    const rt_gate& G = d->gates[i];
+    if (G.csg < -1 || G.csg >= d->n_csg) return fail(RT_ERR_INVALID, "gate CSG index out of range");
+    // A group below an operator lies below the same operator as its parent group, or below one nested in it
+    // (an operator between the two groups); a group outside every operator has no parent inside one.
+    if (G.parent >= 0) {
+      const int pc = d->gates[G.parent].csg;
+      int a = G.csg;
+      while (a >= 0 && a != pc) a = d->csg[a].parent;
+      if (a != pc) return fail(RT_ERR_INVALID, "gate CSG operator does not lie below its parent gate's");
+    }
+  }
   for (int i = 0; i < d->n_patterns; i++) {
     const rt_pattern& p = d->patterns[i];
     if (!affine(p.inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) pattern transform");
@@ -2078,6 +2132,13 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     if (L.csg < -1 || L.csg >= d->n_csg) return fail(RT_ERR_INVALID, "leaf CSG index out of range");
     if (L.csg >= 0 && (i < d->csg[L.csg].first_leaf || i >= d->csg[L.csg].first_leaf + d->csg[L.csg].n_leaves))
       return fail(RT_ERR_INVALID, "leaf outside the leaf range of its CSG operator");
+    if (L.gate >= 0) {
+      // the leaf's innermost operator is its group's, or one nested below the group's
+      const int gc = d->gates[L.gate].csg;
+      int a = L.csg;
+      while (a >= 0 && a != gc) a = d->csg[a].parent;
+      if (a != gc) return fail(RT_ERR_INVALID, "leaf CSG operator does not lie below its gate's");
+    }
     bool tri = L.type == RT_TRIANGLE || L.type == RT_SMOOTH_TRIANGLE;
     if (tri && (L.tri < 0 || L.tri >= d->n_triangles)) return fail(RT_ERR_INVALID, "leaf triangle out of range");
   }
@@ -2091,6 +2152,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   s->last_stream = s->stream;
   HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&s->copy_order, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&s->copy_order2, hipEventDisableTiming));
 
   // ---- acceleration structure
   auto t0 = std::chrono::steady_clock::now();
@@ -2247,7 +2309,9 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   }
   if ((rc = upload(s, b.band_prims, &s->dev.band_prims))) return rc;
   s->dev.n_bands = (int32_t)b.bands.size();
-  if (getenv("RT_AMD_TIMING_NO_BANDS")) s->dev.n_bands = 0;  // timing experiment only: drops the cones' parallel-ray hits
+#ifdef RT_DIAG_NO_BANDS  // diagnostic builds only (timing of the band list): drops the cones' parallel-ray hits
+  if (getenv("RT_AMD_TIMING_NO_BANDS")) s->dev.n_bands = 0;
+#endif
   if (getenv("RT_AMD_BAND_GRID_HOST")) {  // the host builder (what the device builder is checked against)
     BandGrid grid = build_band_grid(b.bands, (size_t)1 << 29);  // at most 2 GiB of entries
     s->dev.band_grid_n = grid.n;
@@ -3006,15 +3070,29 @@ extern "C" int rt_scene_copy_stream(rt_scene* s, void** hip_stream) {
   return RT_OK;
 }
 
+// The copy stream waits for everything enqueued so far on after_stream, or, when none is given, on both
+// render streams (asynchronous frames alternate between them).
+static int order_copy_stream(rt_scene* s, void* after_stream) {
+  if (after_stream) {
+    HIP_TRY(hipEventRecord(s->copy_order, (hipStream_t)after_stream));
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order, 0));
+    return RT_OK;
+  }
+  HIP_TRY(hipEventRecord(s->copy_order, s->stream));
+  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order, 0));
+  HIP_TRY(hipEventRecord(s->copy_order2, s->frame_stream));
+  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order2, 0));
+  return RT_OK;
+}
+
 extern "C" int rt_download_2d(rt_scene* s, const void* src_dev, void* dst_host, uint64_t row_bytes, uint64_t rows,
                               uint64_t pitch, void* after_stream) {
   if (!s || (row_bytes && rows && (!src_dev || !dst_host))) return fail(RT_ERR_INVALID, "null argument");
   if (pitch < row_bytes) return fail(RT_ERR_INVALID, "pitch smaller than a row");
   HIP_TRY(hipSetDevice(s->device));
   if (row_bytes == 0 || rows == 0) return RT_OK;
-  hipStream_t after = after_stream ? (hipStream_t)after_stream : s->last_stream;
-  HIP_TRY(hipEventRecord(s->copy_order, after));
-  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order, 0));
+  int rco = order_copy_stream(s, after_stream);
+  if (rco) return rco;
   HIP_TRY(hipMemcpy2DAsync(dst_host, pitch, src_dev, pitch, row_bytes, rows, hipMemcpyDeviceToHost, s->copy_stream));
   return RT_OK;
 }
@@ -3023,9 +3101,8 @@ extern "C" int rt_download(rt_scene* s, const void* src_dev, void* dst_host, uin
   if (!s || (bytes && (!src_dev || !dst_host))) return fail(RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(s->device));
   if (bytes == 0) return RT_OK;
-  hipStream_t after = after_stream ? (hipStream_t)after_stream : s->last_stream;
-  HIP_TRY(hipEventRecord(s->copy_order, after));
-  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order, 0));
+  int rco = order_copy_stream(s, after_stream);
+  if (rco) return rco;
   // a plain asynchronous copy: the runtime moves it with a DMA engine, which leaves the compute units
   // to the frame that renders meanwhile (a copy kernel of our own measured 40 % slower frames)
   HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s->copy_stream));
