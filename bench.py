@@ -1,100 +1,249 @@
 #!/usr/bin/env python3
 """Headline benchmark: rays/sec and ms/frame on scenes/teapot.json at 1920x1080.
 
-One step = one frame: every rank renders its interleaved 32x32 tiles of the
-image on its own GPU (scene replicated per GPU), then the framebuffer is
-gathered on rank 0 (RCCL gather of the compact tile buffers).  The headline
-value leaves the finished frames in rank 0's HBM; a second timed leg also
-copies every frame to pinned host memory and is reported as `with_host_copy`
-(at 1080p that leg measures the PCIe link).  `python bench.py` runs one GPU;
-for N > 1 it is launched by torch.distributed.run with one rank per GPU.
+One step = one frame, timed from ray generation to the framebuffer on the host: every GPU renders
+its bands of 32 pixel rows of the image (scene replicated per GPU, built once and cloned) and copies
+exactly those bands over its own PCIe link into one page-locked host frame; there is no GPU-to-GPU
+exchange.  `python bench.py --gpus N` is one process that drives N GPUs with one native worker thread
+per GPU (the host library's FrameLoop, the many-frame form of parallel_render, src/parallel.rs:183-204).
+With fewer GPUs than N the parts are dealt round-robin over the GPUs there are (a rehearsal; the line
+says so).  Launched by torch.distributed.run with one rank per GPU (WORLD_SIZE > 1) the same frames are
+gathered on rank 0 with an RCCL gather instead (bench_ranks).
 
-A ray is one World::intersect query of the reference algorithm (primary,
-shadow, reflection, refraction).  The scene stays resident in HBM; scene load
-and the BVH build are outside the timed region and reported in `setup`.
+A ray is one World::intersect query of the reference algorithm (primary, shadow, reflection,
+refraction).  The scene stays resident in HBM; scene load and the BVH build are outside the timed
+region and reported in `setup`.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
-FP64_VALU_PEAK = 78.6e12  # MI355X vector FP64, FLOP/s (datasheet)
+FP64_VALU_PEAK = 78.6e12  # MI355X vector FP64, FLOP/s (datasheet; counts an FMA as two)
 HBM_PEAK = 8.0e12         # bytes/s (datasheet)
-L1_RETURN_PEAK = 256 * 64 * 2.4e9  # bytes/s: 64 B per clock per CU from the vector L1 to the registers
 
-# Algorithmic work of the generation kernel, from the traversal counters of one instrumented frame.
-# Operations (counted as the reference counts arithmetic: one per add / mul / compare-select, no FMA
-# credit): per 4-wide BVH node visit four slab tests of 11; per triangle test 46; per quadric test 60
-# plus the 30 of the ray transform; per group gate 36 + 30; per shaded hit 150 (hit point, normal,
-# Phong terms).
-# HBM bytes the algorithm cannot avoid: the scene once per launch, one output pixel (3 B) per camera
-# ray, one ray record written and read back per secondary ray (RECORD_BYTES).  The per-visit record
-# fetches (128-B node, 80-B triangle, 128-B quadric, 160-B gate, ~200 B of shading tables per hit) are
-# re-reads of a scene that fits the 4 MB L2 of every XCD; they are reported as on-chip traffic.
-FLOPS_NODE, FLOPS_TRI, FLOPS_QUAD, FLOPS_GATE, FLOPS_HIT = 4 * 11, 46, 60 + 30, 36 + 30, 150
-BYTES_NODE, BYTES_TRI, BYTES_QUAD, BYTES_GATE, BYTES_HIT = 128, 80, 128, 160, 200
+# Algorithmic work of the generation kernel per traversal event.
+# "survey": the coefficients the measurement plan of this build fixes (flops per 4-wide node visit,
+# triangle test, quadric test, shaded hit); roofline.frac uses these.
+# "f64": what this implementation's f64 arithmetic amounts to per event (a quadric test includes the 30
+# operations of the ray transform, a gate the transform and three slab axes); the box tests of a node
+# visit are single precision here and are counted apart, as f32 operations.
+SURVEY = {"node": 22, "tri": 46, "quad": 60, "hit": 150}
+F64 = {"tri": 46, "quad": 60 + 30, "gate": 36 + 30, "hit": 150}
+F32_PER_NODE = 4 * 11
 BYTES_PIXEL = 3
 RECORD_BYTES = 13 * 8 + 4 * 4  # one ray record of a generation buffer
 
-
-DEPTH = 4  # frames in flight: device frames, host frames and the library's frame slots
-BUCKET = 4  # several ranks: frames per gather (a part of a frame renders faster than a collective starts)
-
-
-def kernel_work(st, scene_bytes):
-    nv = st.node_visits + st.shadow_node_visits
-    tt = st.tri_tests + st.shadow_tri_tests
-    qt = st.quadric_tests + st.shadow_quadric_tests
-    gt = st.gate_tests + st.shadow_gate_tests
-    flops = nv * FLOPS_NODE + tt * FLOPS_TRI + qt * FLOPS_QUAD + gt * FLOPS_GATE + st.shadow * FLOPS_HIT
-    onchip = nv * BYTES_NODE + tt * BYTES_TRI + qt * BYTES_QUAD + gt * BYTES_GATE + st.shadow * BYTES_HIT
-    secondary = st.reflect + st.refract
-    records = (st.primary if secondary else 0) + secondary  # camera rays keep records only when rays are spawned
-    hbm = st.kernel_launches * scene_bytes + st.primary * BYTES_PIXEL + 2 * records * RECORD_BYTES
-    events = {"node_visits": nv, "tri_tests": tt, "quadric_tests": qt, "gate_tests": gt, "shaded_hits": st.shadow}
-    return flops, hbm, onchip, events
+DEPTH = 4     # frames in flight per GPU = host frames in the ring
+PRIMING = 64  # untimed frames before the warmup: first launches load code objects and grow runtime pools
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "teapot.json"))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-download", action="store_true",
-                    help="skip the second leg, which copies every frame to the host (under rocprofv3 the runtime "
-                         "turns the DMA copies into copy kernels that share the GPU with the render kernel)")
-    ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline renders every n-th pixel of every n-th row")
-    args = ap.parse_args()
+def host_cores():
+    """Cores this process may use: its affinity mask, cut down to a cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+        source = "sched_getaffinity"
+    except AttributeError:
+        n, source = os.cpu_count() or 1, "os.cpu_count"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(quota) // int(period) >= 1 and int(quota) // int(period) < n:
+            n, source = int(quota) // int(period), "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("OMP_NUM_THREADS")  # the GPU box states its CPU share per GPU here
+    if env and env.isdigit() and 0 < int(env) < n:
+        n, source = int(env), "OMP_NUM_THREADS (the box's CPU share)"
+    return n, source
 
+
+def sum_stats(stats):
+    keys = ("primary", "shadow", "reflect", "refract", "kernel_ms", "kernel_launches", "node_visits", "tri_tests",
+            "quadric_tests", "gate_tests", "shadow_node_visits", "shadow_tri_tests", "shadow_quadric_tests", "shadow_gate_tests")
+    return {k: sum(getattr(s, k) for s in stats) for k in keys}
+
+
+def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
+    """counted: summed statistics of one instrumented frame (all parts); lone / piped: summed statistics
+    of frames rendered one at a time / in the timed loop."""
+    nv = counted["node_visits"] + counted["shadow_node_visits"]
+    tt = counted["tri_tests"] + counted["shadow_tri_tests"]
+    qt = counted["quadric_tests"] + counted["shadow_quadric_tests"]
+    gt = counted["gate_tests"] + counted["shadow_gate_tests"]
+    hits = counted["shadow"]
+    launches = max(1, counted["kernel_launches"])  # per frame: one per part and generation
+    flops_survey = nv * SURVEY["node"] + tt * SURVEY["tri"] + qt * SURVEY["quad"] + hits * SURVEY["hit"]
+    flops_f64 = tt * F64["tri"] + qt * F64["quad"] + gt * F64["gate"] + hits * F64["hit"]
+    f32_ops = nv * F32_PER_NODE
+    secondary = counted["reflect"] + counted["refract"]
+    records = (counted["primary"] if secondary else 0) + secondary
+    hbm = launches * scene_bytes + counted["primary"] * BYTES_PIXEL + 2 * records * RECORD_BYTES
+    avg_ms = piped["kernel_ms"] / max(1, piped["kernel_launches"])
+    lone_ms = lone["kernel_ms"] / max(1, lone["kernel_launches"])
+    per_launch = flops_survey / launches
+    pmc, traffic = None, None
+    for name, key in (("pmc_f64.json", "f64_ops_per_launch"), ("traffic.json", "hbm_bytes_per_launch")):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                v = json.load(open(path)).get("k_generation", {}).get(key)
+            except Exception:
+                v = None
+            if name.startswith("pmc"):
+                pmc = v
+            else:
+                traffic = v
+    frac = per_launch / (avg_ms * 1e-3) / FP64_VALU_PEAK
+    return {
+        "bound": "fp64_valu", "achieved": per_launch / (avg_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK / 1e12,
+        "unit": "TFLOP/s", "frac": frac, "traffic": traffic,
+        "kernel": "k_generation", "launches_per_frame": launches, "avg_launch_ms": avg_ms, "lone_launch_ms": lone_ms,
+        "flops_per_launch": per_launch,
+        "frac_lone_launch": per_launch / (lone_ms * 1e-3) / FP64_VALU_PEAK,
+        # all GPUs together over the frame period: what the node delivers while launches overlap
+        "frac_per_frame_period": flops_survey / frame_period_s / (FP64_VALU_PEAK * n_parts),
+        "f64_flops_per_launch_this_implementation": flops_f64 / launches,
+        "frac_f64_this_implementation": flops_f64 / launches / (avg_ms * 1e-3) / FP64_VALU_PEAK,
+        "f32_box_test_ops_per_launch": f32_ops / launches,
+        "pmc_f64_ops_per_launch": pmc,
+        "frac_pmc_f64": None if not pmc else pmc / (avg_ms * 1e-3) / FP64_VALU_PEAK,
+        "hbm_bytes_per_launch": hbm / launches, "frac_hbm": hbm / launches / (avg_ms * 1e-3) / HBM_PEAK,
+        "events_per_frame": {"node_visits": nv, "tri_tests": tt, "quadric_tests": qt, "gate_tests": gt, "shaded_hits": hits},
+        "coefficients": {"frac": SURVEY, "f64_this_implementation": F64, "f32_per_node_visit": F32_PER_NODE},
+        "note": "no dense contraction on this path, so no MFMA: the ceiling is vector FP64 (78.6 TFLOP/s datasheet, an FMA "
+                "counted as two; the path is compiled without contraction to match the reference bit for bit, so half of "
+                "that is reachable). frac prices the events of one instrumented frame with the plan's coefficients "
+                "(node 22, triangle 46, quadric 60, shaded hit 150) over avg_launch_ms, the mean k_generation duration of "
+                "the timed loop from HIP events on the library's streams; launches of consecutive frames overlap on two "
+                "streams, so avg_launch_ms exceeds both lone_launch_ms and the frame period (profiles/ holds the kernel "
+                "timeline). hbm_bytes_per_launch is the traffic the algorithm cannot avoid (scene once, pixels, ray "
+                "records); the per-visit record fetches are cache hits.",
+    }
+
+
+def bench_single_process(args):
+    pkg = load_package()
+    have = pkg.bindings.device_count()
+    if have < 1:
+        raise SystemExit("no GPU visible")
+    n = args.gpus
+    devices = [k % have for k in range(n)]
+    W, H = args.width, args.height
+    t_load = time.perf_counter()
+    scene = pkg.Scene.from_file(args.scene, base_dir=ROOT, device=None)  # host side only; the loop owns the GPU copies
+    scene.set_canvas(W, H)
+    loop = scene.frame_loop(devices, depth=DEPTH)
+    load_s = time.perf_counter() - t_load
+    info, linfo = scene.info(), loop.info()
+
+    # The timed region of the metric: frames on the host.  Then the same frames left in HBM, frames
+    # rendered one at a time (lone launches), and one instrumented frame.
+    if args.hbm_only:  # profiling aid: rocprofv3 turns the DMA copies into copy kernels that share the GPU with the render
+        host_s, host_stats = loop.run(PRIMING + args.warmup, args.steps, False)
+        sha, hbm_s = None, None
+    else:
+        host_s, host_stats = loop.run(PRIMING + args.warmup, args.steps, True)
+        frame = loop.host_frame((PRIMING + args.warmup + args.steps - 1) % DEPTH)
+        sha = hashlib.sha256(frame.tobytes()).hexdigest()
+        hbm_s = None if args.no_hbm_leg else loop.run(PRIMING + args.warmup, args.steps, False)[0]
+    lone = sum_stats(loop.blocking_frames(10, False))
+    counted = sum_stats(loop.blocking_frames(1, True))
+    piped = sum_stats(host_stats)
+    rays_per_frame = (piped["primary"] + piped["shadow"] + piped["reflect"] + piped["refract"]) / args.steps
+    roofline = roofline_of(counted, lone, piped, linfo["scene_bytes"], host_s / args.steps, n)
+
+    cpu_baseline = None
+    if n == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle as orc  # test infrastructure, used here only as the timed CPU baseline
+
+        cores, source = host_cores()
+        ref = orc.OracleScene.from_file(args.scene, base_dir=ROOT)
+        ref.set_canvas(W, H)
+        s = args.cpu_stride
+        c0 = time.perf_counter()
+        res = ref.render(jobs=cores, xstep=s, ystep=s)
+        cpu_s = time.perf_counter() - c0
+        cpu_rays = sum(res["counts"])
+        c1 = time.perf_counter()
+        res1 = ref.render(jobs=1, xstep=2 * s, ystep=2 * s)
+        cpu1_s = time.perf_counter() - c1
+        cpu_baseline = {"value": cpu_rays / cpu_s, "unit": "rays/s", "cores": cores, "kind": "port",
+                        "cores_from": source, "cpus_of_the_machine": os.cpu_count(),
+                        "single_core_value": sum(res1["counts"]) / cpu1_s,
+                        "sample": "C++ restatement of the reference algorithm (group box gate + linear scan of all %d "
+                                  "triangles per ray), -j %d = every core this process may use, every %dth pixel of every "
+                                  "%dth row of the same %dx%d frame: %d rays in %.2f s" % (
+                                      info["triangles"], cores, s, s, W, H, cpu_rays, cpu_s)}
+
+    out = {
+        "metric": "rays/sec (node) on scenes/teapot.json at 1080p",
+        "value": rays_per_frame * args.steps / host_s,
+        "unit": "rays/s",
+        "n_gpus": n,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": host_s / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s at %dx%d: generated models/teapot.obj (%d smooth triangles in %d groups) + floor plane, "
+                        "one point light, recursion depth 5" % (os.path.relpath(args.scene, ROOT), W, H, info["triangles"], info["gates"]),
+            "rays_per_frame": rays_per_frame,
+            "timed_region": "frames left in HBM (--hbm-only: a profiling run, not the metric's region)" if args.hbm_only
+                            else "ray generation to the finished frame in page-locked host memory",
+            "parallelism": "one process, %d part(s) = bands of 32 pixel rows dealt round-robin, one worker thread, one scene copy "
+                           "and one PCIe link per GPU, all parts copied into one shared host frame; no collective" % n,
+            "devices": devices,
+            "rehearsal": have < n,
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu_baseline,
+        "frames_left_in_hbm": None if hbm_s is None else {
+            "value": rays_per_frame * args.steps / hbm_s, "unit": "rays/s", "ms_per_step": hbm_s / args.steps * 1e3,
+            "note": "the same loop without the copies to the host (not the metric's timed region)"},
+        "PCIe_GBps": W * H * 3 * args.steps / host_s / 1e9,
+        "breakdown_ms": {"frame": host_s / args.steps * 1e3, "generation_kernels_per_frame": piped["kernel_ms"] / args.steps,
+                         "lone_frame_kernel": lone["kernel_ms"] / 10},
+        "pipeline": {"frames_in_flight_per_gpu": DEPTH, "untimed_priming_frames": PRIMING},
+        "frame_sha256": sha,
+        "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": linfo["build_seconds"], "scene_bytes": linfo["scene_bytes"],
+                  "bvh_builds": 1},
+    }
+    if have < n:
+        out["config"]["note"] = "only %d GPU(s) visible: the %d parts share them, so this line rehearses the path and is no scaling figure" % (have, n)
+    print(json.dumps(out))
+    loop.close()
+
+
+def bench_ranks(args, world):
+    """One rank per GPU under torch.distributed: every rank renders its interleaved 32x32 tiles in the
+    compact layout, rank 0 gathers them (one RCCL gather per BUCKET frames) and copies every frame to
+    pinned host memory."""
+    import torch
+    import torch.distributed as dist
+
+    BUCKET = 4
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (
-            args.gpus, world, args.gpus))
     # RT_BENCH_BACKEND=gloo rehearses the multi-rank path on a machine with fewer GPUs than ranks
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group(backend)
 
     pkg = load_package()
     t_load = time.perf_counter()
@@ -103,16 +252,11 @@ def main():
     load_s = time.perf_counter() - t_load
     info, foot = scene.info(), scene.footprint()
     W, H = args.width, args.height
-
-    # DEPTH device frames and DEPTH pinned host frames: in the host-copy leg the copy of frame k runs
-    # on its own stream while later frames render.  With several ranks every rank renders its tiles in
-    # the compact layout and rank 0 gathers them (one RCCL gather + one indexed copy).
-    slots = DEPTH if world == 1 else 2 * BUCKET  # several ranks: one bucket renders while the other is gathered
-    gather = pkg.tiles.FrameGather(W, H, device, rank, world, depth=slots, bucket=1 if world == 1 else BUCKET)
-    frames = [torch.zeros((H, W, 3), dtype=torch.uint8, device=device) for _ in range(DEPTH)] if world == 1 else None
+    slots = 2 * BUCKET  # one bucket renders while the other is gathered
+    gather = pkg.tiles.FrameGather(W, H, device, rank, world, depth=slots, bucket=BUCKET)
     host_frames = [torch.empty((H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(slots)] if rank == 0 else None
-    copy_stream = torch.cuda.ExternalStream(scene.copy_stream_ptr(), device=device)  # the library's copy stream
-    buffer_free = [torch.cuda.Event() for _ in range(slots)]  # several ranks: one per bucket, at its first slot
+    copy_stream = torch.cuda.ExternalStream(scene.copy_stream_ptr(), device=device)
+    buffer_free = [torch.cuda.Event() for _ in range(slots)]
     rendered = [torch.cuda.Event() for _ in range(slots)]
     stream_objects = {}
 
@@ -123,30 +267,6 @@ def main():
         return stream_objects[p]
 
     step_no = [0]
-
-    def step(download):
-        # Frames are enqueued, not waited for (the scene spawns no rays, so a frame is one kernel):
-        # render k + 1 runs while frame k is gathered and copied; the streams are ordered by events.
-        step_no[0] += 1
-        if world == 1:
-            k = (step_no[0] - 1) % DEPTH
-            buffer_free[k].synchronize()  # frame k - DEPTH has left these buffers (at most DEPTH frames in flight)
-            frame = frames[k]
-            scene.render_device(rgb8_ptr=frame.data_ptr(), wait=False)
-            if download:
-                scene.download(frame.data_ptr(), host_frames[k].data_ptr(), frame.numel())  # framebuffer on the host
-                buffer_free[k].record(copy_stream)
-            else:
-                buffer_free[k].record(render_stream())
-            return
-        # several ranks: render into slot k of the current bucket; the bucket's last frame gathers it
-        k = (step_no[0] - 1) % slots
-        if k % BUCKET == 0:
-            buffer_free[k].synchronize()  # the bucket's last gather (and host copies) are done
-        scene.render_device(rgb8_ptr=gather.mine[k].data_ptr(), part=rank, n_parts=world, wait=False, compact=True)
-        rendered[k].record(render_stream())
-        if k % BUCKET == BUCKET - 1:
-            finish_bucket(k // BUCKET, download)
 
     def finish_bucket(b, download):
         first = b * BUCKET
@@ -162,21 +282,27 @@ def main():
         else:
             buffer_free[first].record()
 
+    def step(download):
+        step_no[0] += 1
+        k = (step_no[0] - 1) % slots
+        if k % BUCKET == 0:
+            buffer_free[k].synchronize()  # the bucket's last gather (and host copies) are done
+        scene.render_device(rgb8_ptr=gather.mine[k].data_ptr(), part=rank, n_parts=world, wait=False, compact=True)
+        rendered[k].record(render_stream())
+        if k % BUCKET == BUCKET - 1:
+            finish_bucket(k // BUCKET, download)
+
     def flush(download):
-        """Several ranks: gathers a bucket the loop left partly filled (its other slots hold older frames)."""
-        if world > 1 and step_no[0] % BUCKET:
+        if step_no[0] % BUCKET:
             finish_bucket(((step_no[0] - 1) % slots) // BUCKET, download)
             step_no[0] += BUCKET - step_no[0] % BUCKET
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
 
     def timed_loop(download, priming):
-        """`priming` untimed frames, then args.steps timed ones between two barriers.  Returns the
-        elapsed seconds (max over ranks) and this rank's summed frame statistics."""
         for _ in range(priming):
             step(download)
         flush(download)
@@ -186,144 +312,68 @@ def main():
         for _ in range(args.steps):
             step(download)
         flush(download)
-        t_enq = time.perf_counter() - t0
-        stats = scene.wait()  # all frames rendered; sums of their ray counts and kernel times
-        t_wait = time.perf_counter() - t0
-        sync()                # ... and gathered (and copied to the host)
+        stats = scene.wait()
+        sync()
         dt = time.perf_counter() - t0
-        if os.environ.get("RT_BENCH_DEBUG"):
-            print("download=%s: enqueue %.3f ms, +wait %.3f ms, +sync %.3f ms" % (
-                download, t_enq * 1e3, t_wait * 1e3, dt * 1e3), file=sys.stderr)
         t_max = torch.tensor([dt], dtype=torch.float64, device=device)
-        if world > 1:
-            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         return float(t_max.item()), stats
 
-    # Two timed legs over the same frames.  The headline leaves every finished frame in HBM (rank 0's,
-    # after the gather); the second leg also moves every frame to pinned host memory, which at 1080p is
-    # bound by the PCIe link (6.2 MB per frame), not by the render.
-    # 64 priming frames: first launches load code objects and grow runtime pools.
-    elapsed, st = timed_loop(False, 64 + args.warmup)
-    host_elapsed = None
-    if not args.no_download:
-        host_elapsed, _ = timed_loop(True, 64 + args.warmup)
-    kernel_ms, kernel_n = st.kernel_ms, st.kernel_launches
-
+    host_elapsed, st = timed_loop(True, PRIMING + args.warmup)
+    hbm_elapsed, _ = timed_loop(False, PRIMING + args.warmup)
     rays_step = torch.tensor([float(st.rays) / args.steps], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(rays_step, op=dist.ReduceOp.SUM)
+    dist.all_reduce(rays_step, op=dist.ReduceOp.SUM)
     rays_per_frame = float(rays_step.item())
+    scratch = torch.zeros((H, W, 3), dtype=torch.uint8, device=device)
+    counted = sum_stats([scene.render_device(rgb8_ptr=scratch.data_ptr(), part=rank, n_parts=world, counters=True)])
+    lone = sum_stats([scene.render_device(rgb8_ptr=scratch.data_ptr(), part=rank, n_parts=world) for _ in range(10)])
+    roofline = roofline_of(counted, lone, sum_stats([st]), foot["scene_bytes"], host_elapsed / args.steps, 1)
+    roofline["scope"] = "rank 0's part of the frame"
+    if rank == 0:
+        print(json.dumps({
+            "metric": "rays/sec (node) on scenes/teapot.json at 1080p",
+            "value": rays_per_frame * args.steps / host_elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": host_elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "%s at %dx%d: generated models/teapot.obj (%d smooth triangles in %d groups) + floor plane, "
+                            "one point light, recursion depth 5" % (os.path.relpath(args.scene, ROOT), W, H, info["triangles"], info["gates"]),
+                "rays_per_frame": rays_per_frame,
+                "timed_region": "ray generation to the finished frame in page-locked host memory of rank 0",
+                "parallelism": "one rank per GPU, interleaved 32x32 tiles, scene replicated, one RCCL gather per %d frames on "
+                               "rank 0, then rank 0's DMA to the host" % BUCKET},
+            "roofline": roofline, "cpu_baseline": None,
+            "frames_left_in_hbm": {"value": rays_per_frame * args.steps / hbm_elapsed, "unit": "rays/s",
+                                   "ms_per_step": hbm_elapsed / args.steps * 1e3},
+            "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": foot["build_seconds"], "scene_bytes": foot["scene_bytes"]},
+        }))
+    dist.destroy_process_group()
 
-    # ---- roofline of the dominant kernel (k_generation, this rank's part): duration from the HIP
-    # events the library records on its stream around every launch of the timed loop; work from one
-    # extra, instrumented frame
-    scratch = frames[0] if world == 1 else torch.zeros((H, W, 3), dtype=torch.uint8, device=device)
-    cst = scene.render_device(rgb8_ptr=scratch.data_ptr(), part=rank, n_parts=world, counters=True)
-    flops, nbytes, onchip, events = kernel_work(cst, foot["scene_bytes"])
-    launches = max(1, cst.kernel_launches)
-    avg_ms = kernel_ms / max(1, kernel_n)
-    avg_s = avg_ms * 1e-3
-    fl, by = flops / launches, nbytes / launches
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("k_generation", {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    frac_valu, frac_hbm = fl / avg_s / FP64_VALU_PEAK, by / avg_s / HBM_PEAK
-    if frac_valu >= frac_hbm:
-        roofline = {"bound": "fp64_valu", "achieved": fl / avg_s / 1e12, "peak": FP64_VALU_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": frac_valu, "traffic": traffic}
-    else:
-        roofline = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": frac_hbm, "traffic": traffic}
-    roofline.update({
-        "kernel": "k_generation", "avg_launch_ms": avg_ms, "launches_per_frame": launches,
-        "flops_per_launch": fl, "bytes_per_launch": by, "frac_fp64_valu": frac_valu, "frac_hbm": frac_hbm,
-        "onchip_bytes_per_launch": onchip / launches, "onchip_GBps": onchip / launches / avg_s / 1e9,
-        "frac_l1_return": onchip / launches / avg_s / L1_RETURN_PEAK,
-        # the same work over the time the GPU actually spends per launch when launches overlap (frame period)
-        "frac_fp64_valu_per_frame_period": flops / (elapsed / args.steps) / FP64_VALU_PEAK,
-        "events_per_frame": events,
-        "overlap": "up to four frames are in flight on two streams, so a launch shares the GPU with its neighbours: "
-                   "avg_launch_ms is longer than a lone launch (about 0.17 ms) while frames complete faster -- a lone "
-                   "launch leaves about a third of the wave slots empty",
-        "note": "no dense contraction on this path, so no MFMA: the ceilings are vector FP64 (78.6 TFLOP/s datasheet, "
-                "which counts an FMA as two; the path is compiled without contraction to match the reference bit for "
-                "bit, so half of that is reachable) and HBM (8 TB/s). bytes_per_launch is the unavoidable HBM traffic "
-                "(scene once, pixels, ray records); the per-visit record fetches of the %.1f MB scene are served by "
-                "L1 / L2 and listed as onchip_bytes; they are priced against the L1 -> register return path "
-                "(64 B / clock / CU, 39 TB/s), which the counters show as the busiest unit (TD busy 76 %%): a wave "
-                "load returns 1 KB whatever its lanes address" % (foot["scene_bytes"] / 1e6),
-    })
 
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    cpu_baseline = None
-    if world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle as orc  # test infrastructure, used here only as the timed CPU baseline
-
-        cores = min(16, os.cpu_count() or 1)
-        ref = orc.OracleScene.from_file(args.scene, base_dir=ROOT)
-        ref.set_canvas(W, H)
-        s = args.cpu_stride
-        c0 = time.perf_counter()
-        res = ref.render(jobs=cores, xstep=s, ystep=s)
-        cpu_s = time.perf_counter() - c0
-        cpu_rays = sum(res["counts"])
-        c1 = time.perf_counter()
-        res1 = ref.render(jobs=1, xstep=2 * s, ystep=2 * s)
-        cpu1_s = time.perf_counter() - c1
-        cpu_baseline = {"value": cpu_rays / cpu_s, "unit": "rays/s", "cores": cores, "kind": "port",
-                        "single_core_value": sum(res1["counts"]) / cpu1_s,
-                        "sample": "C++ restatement of the reference algorithm (group box gate + linear scan of all %d "
-                                  "triangles per ray), -j %d, every %dth pixel of every %dth row of the same %dx%d frame: "
-                                  "%d rays in %.2f s" % (info["triangles"], cores, s, s, W, H, cpu_rays, cpu_s)}
-
-    out = {
-        "metric": "rays/sec (node) on scenes/teapot.json at 1080p",
-        "value": rays_per_frame * args.steps / elapsed,
-        "unit": "rays/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": "%s at %dx%d: generated models/teapot.obj (%d smooth triangles in %d groups) + floor plane, "
-                        "one point light, recursion depth 5" % (os.path.relpath(args.scene, ROOT), W, H, info["triangles"], info["gates"]),
-            "rays_per_frame": rays_per_frame,
-            "parallelism": "interleaved 32x32 tiles over %d GPU(s), scene replicated, framebuffer gather on rank 0%s" % (
-                world, "" if world == 1 else " (one RCCL gather per %d frames)" % BUCKET),
-        },
-        "roofline": roofline,
-        "cpu_baseline": cpu_baseline,
-        "with_host_copy": None if host_elapsed is None else {
-            "value": rays_per_frame * args.steps / host_elapsed, "unit": "rays/s",
-            "ms_per_step": host_elapsed / args.steps * 1e3,
-            "PCIe_GBps": W * H * 3 * args.steps / host_elapsed / 1e9,
-            "note": "the same loop with every finished frame also copied to pinned host memory by DMA on a third "
-                    "stream (from rank 0): bound by the PCIe link (about 43 GB/s device to host measured on this "
-                    "pool), not by the render"},
-        "breakdown_ms": {"frame": elapsed / args.steps * 1e3, "generation_kernels": kernel_ms / args.steps},
-        "pipeline": {"frames_in_flight": DEPTH, "frames_per_gather": None if world == 1 else BUCKET,
-                     "untimed_priming_frames": 64,
-                     "note": "frames are enqueued on two alternating streams and stay in HBM (rank 0's after the "
-                             "gather); a frame is waited for only when its buffers are needed again"},
-        "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": foot["build_seconds"], "scene_bytes": foot["scene_bytes"]},
-    }
-    print(json.dumps(out))
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "teapot.json"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the extra leg that leaves the frames in HBM")
+    ap.add_argument("--hbm-only", action="store_true",
+                    help="time only the loop that leaves the frames in HBM (for profiler runs: under rocprofv3 the runtime "
+                         "turns the DMA copies to the host into copy kernels that share the GPU with the render kernel)")
+    ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline renders every n-th pixel of every n-th row")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
-        dist.destroy_process_group()
+        if world != args.gpus:
+            raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world))
+        bench_ranks(args, world)
+    else:
+        bench_single_process(args)
 
 
 if __name__ == "__main__":

@@ -213,6 +213,13 @@ int rt_device_count(void);
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
+/* A copy of `scene` on `device` (the same GPU or another one of this process): the acceleration structure
+ * is not built again, its arrays are copied device to device.  The copy is independent of the original
+ * (own streams, own frames in flight) and is released with rt_scene_destroy.  This is how a host that
+ * renders one frame on several GPUs (src/parallel.rs:183-204 hands one Arc<World> to all its workers)
+ * pays for one build. */
+int rt_scene_clone(const rt_scene* scene, int device, rt_scene** out);
+
 /* Device bytes held by the scene data (acceleration structure included), and
  * the host seconds spent building the acceleration structure. */
 int rt_scene_footprint(const rt_scene* scene, uint64_t* scene_bytes, double* build_seconds);
@@ -236,7 +243,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, u
 /* Frames of a render loop, back to back.  With RT_FLAG_ASYNC, rt_render enqueues the frame on the
  * scene's stream and returns at once (stats is not written); at most four frames are in flight, a
  * fifth call waits for the oldest.  A scene whose materials spawn reflection or refraction rays
- * needs the host between generations, so there the flag is ignored and the call blocks as usual.
+ * needs the host between generations, so there the call blocks as usual (its counts still go to rt_scene_wait).
  * rt_scene_wait blocks until every enqueued frame is complete and returns the sums of their ray
  * counts, kernel time and kernel launches since the previous wait (render_ms is not filled).
  * Asynchronous frames alternate between two streams of the scene.  rt_download / rt_download_2d without
@@ -268,10 +275,22 @@ int rt_scene_copy_stream(rt_scene* scene, void** hip_stream);
 int rt_download_2d(rt_scene* scene, const void* src_dev, void* dst_host, uint64_t row_bytes, uint64_t rows,
                    uint64_t pitch, void* after_stream);
 
+/* Fences on the copy stream, for a host that reuses frame buffers in a ring: rt_copy_fence marks the point
+ * the copy stream has reached (after the downloads enqueued so far) under `slot` (0..7); rt_copy_wait
+ * blocks until the copy stream has passed the mark last set under `slot` (returns at once when none was
+ * set).  No counterpart in the reference, whose canvas is written under a mutex (src/parallel.rs:48). */
+int rt_copy_fence(rt_scene* scene, uint32_t slot);
+int rt_copy_wait(rt_scene* scene, uint32_t slot);
+
 /* Page-locked host memory usable from every GPU of the process (NULL when it cannot be had): frames
  * in it are filled by DMA at full PCIe speed.  The reference's canvas is a plain Vec (src/canvas.rs:22-28). */
 void* rt_host_alloc(uint64_t bytes);
 void rt_host_free(void* p);
+
+/* Device memory on `device` for the frames rt_render writes (zero-filled), for hosts that do not link a
+ * GPU runtime of their own.  The reference's canvas is a plain Vec (src/canvas.rs:22-28). */
+int rt_device_alloc(int device, uint64_t bytes, void** out);
+void rt_device_free(int device, void* p);
 
 /* Same, into host buffers (the library stages through device memory).  With RT_FLAG_BANDS only the
  * part's own bands are copied to the host buffers, so the parts of one frame, rendered by different

@@ -123,6 +123,18 @@ def libraries():
     host.rth_canvas_pixels.argtypes = [vp]
     host.rth_canvas_pixels.restype = dp
     host.rth_canvas_save.argtypes = [vp, C.c_char_p]
+    host.rth_frame_loop_new.argtypes = [vp, u64, C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
+    host.rth_frame_loop_free.argtypes = [vp]
+    host.rth_frame_loop_run.argtypes = [vp, u64, u64, C.c_int32, dp, C.POINTER(RtStats)]
+    host.rth_frame_loop_blocking.argtypes = [vp, u64, C.c_int32, C.POINTER(RtStats)]
+    host.rth_frame_loop_host_frame.argtypes = [vp, C.c_int32]
+    host.rth_frame_loop_host_frame.restype = vp
+    host.rth_frame_loop_info.argtypes = [vp, C.POINTER(u64), dp]
+    amd.rt_scene_clone.argtypes = [vp, i32, C.POINTER(vp)]
+    amd.rt_copy_fence.argtypes = [vp, u32]
+    amd.rt_copy_wait.argtypes = [vp, u32]
+    amd.rt_device_alloc.argtypes = [i32, u64, C.POINTER(vp)]
+    amd.rt_device_free.argtypes = [i32, vp]
     host.rth_ppm_encode.argtypes = [u64, u64, vp, vp, u64]
     host.rth_ppm_encode.restype = u64
     _libs = (amd, host)
@@ -224,6 +236,66 @@ class Canvas:
         rc = self._host.rth_canvas_save(self._c, str(path).encode())
         if rc != 0:
             raise RtError(rc, self._host.rth_last_error().decode())
+
+
+class FrameLoop:
+    """The host library's render loop over several GPUs of this process (host/rt_host.hpp FrameLoop):
+    one worker thread and one copy of the scene per part, each GPU copying its own bands of 32 pixel
+    rows into a ring of page-locked host frames shared by all parts."""
+
+    def __init__(self, scene, devices, depth=4):
+        _, self._host = libraries()
+        self._scene = scene  # keeps the World alive
+        self.devices = [int(d) for d in devices]
+        self.depth = depth
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        rc = self._host.rth_frame_loop_new(scene._h, len(self.devices), arr, depth, C.byref(h))
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
+        self._l = h
+        cam = scene.camera()
+        self.width, self.height = cam.hsize, cam.vsize
+
+    def close(self):
+        if getattr(self, "_l", None):
+            self._host.rth_frame_loop_free(self._l)
+            self._l = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, warmup, frames, to_host=True):
+        """Returns (seconds of the timed frames, [RtStats per part])."""
+        sec = C.c_double()
+        stats = (RtStats * len(self.devices))()
+        rc = self._host.rth_frame_loop_run(self._l, warmup, frames, 1 if to_host else 0, C.byref(sec), stats)
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
+        return sec.value, list(stats)
+
+    def blocking_frames(self, frames=1, counters=False):
+        """Frames rendered one at a time, nothing overlapping; [RtStats per part], summed over the frames."""
+        stats = (RtStats * len(self.devices))()
+        rc = self._host.rth_frame_loop_blocking(self._l, frames, 1 if counters else 0, stats)
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
+        return list(stats)
+
+    def host_frame(self, slot):
+        """(H, W, 3) uint8 view of ring slot `slot` (page-locked memory owned by the loop)."""
+        p = self._host.rth_frame_loop_host_frame(self._l, slot)
+        buf = (C.c_uint8 * (self.width * self.height * 3)).from_address(p)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 3)
+
+    def info(self):
+        out = (C.c_uint64 * 2)()
+        b = C.c_double()
+        self._host.rth_frame_loop_info(self._l, out, C.byref(b))
+        return {"scene_bytes": int(out[0]), "frame_bytes": int(out[1]), "build_seconds": b.value}
 
 
 class Scene:
@@ -383,6 +455,10 @@ class Scene:
         if rc != 0:
             raise RtError(rc, self._host.rth_last_error().decode())
         return Canvas(_handle=h)
+
+    def frame_loop(self, devices, depth=4):
+        """parallel_render's workers kept alive over frames: part k of len(devices) on GPU devices[k]."""
+        return FrameLoop(self, devices, depth)
 
     # ---- batch forms of the reference's per-ray API
     def ray_for_pixel(self, xy):

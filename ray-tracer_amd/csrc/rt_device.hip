@@ -1629,8 +1629,18 @@ struct rt_scene {
   hipStream_t last_stream = nullptr;   // where the most recent frame was enqueued
   hipStream_t copy_stream = nullptr;   // rt_download
   hipEvent_t copy_order = nullptr, copy_order2 = nullptr;
+  static constexpr int COPY_FENCES = 8;
+  hipEvent_t copy_fence[COPY_FENCES] = {};  // rt_copy_fence / rt_copy_wait
+  bool copy_fence_set[COPY_FENCES] = {};
   SceneDev dev{};
-  std::vector<void*> allocs;
+  // device arrays of the scene data: address, size, and which pointer of `dev` holds the address
+  // (byte offset inside SceneDev), so that rt_scene_clone can rebuild `dev` on another GPU
+  struct Alloc {
+    void* p;
+    size_t bytes;
+    size_t field;
+  };
+  std::vector<Alloc> allocs;
   uint64_t scene_bytes = 0;
   double build_seconds = 0;
   int stack_need = 1;
@@ -1673,13 +1683,14 @@ struct rt_scene {
 
 namespace {
 
+// `out` points at one of the pointers inside s->dev
 template <class T>
 int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
   *out = nullptr;
   if (v.empty()) return RT_OK;
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
-  s->allocs.push_back(p);
+  s->allocs.push_back(rt_scene::Alloc{p, v.size() * sizeof(T), (size_t)((const char*)out - (const char*)&s->dev)});
   HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   s->scene_bytes += v.size() * sizeof(T);
   *out = (const T*)p;
@@ -2026,7 +2037,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   // before any of the memory they use is released
   for (hipStream_t st : {s->stream, s->frame_stream, s->copy_stream})
     if (st) (void)hipStreamSynchronize(st);
-  for (void* p : s->allocs) (void)hipFree(p);
+  for (const rt_scene::Alloc& a : s->allocs) (void)hipFree(a.p);
   for (GenBuf& g : s->gens)
     if (g.slab) (void)hipFree(g.slab);
   if (s->d_counts) (void)hipFree(s->d_counts);
@@ -2049,12 +2060,40 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   }
   if (s->copy_order) (void)hipEventDestroy(s->copy_order);
   if (s->copy_order2) (void)hipEventDestroy(s->copy_order2);
+  for (hipEvent_t e : s->copy_fence)
+    if (e) (void)hipEventDestroy(e);
   if (s->frame_stream) {
     (void)hipStreamSynchronize(s->frame_stream);
     (void)hipStreamDestroy(s->frame_stream);
   }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
+}
+
+// Streams, events and the per-frame counters of a scene on `device` (which becomes current).
+static int scene_runtime_init(rt_scene* s, int device) {
+  HIP_TRY(hipSetDevice(device));
+  s->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&s->frame_stream, hipStreamNonBlocking));
+  s->last_stream = s->stream;
+  HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&s->copy_order, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&s->copy_order2, hipEventDisableTiming));
+  for (hipEvent_t& e : s->copy_fence) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipMalloc((void**)&s->d_counts, COUNT_WORDS * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc((void**)&s->d_stats, STAT_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_counts, COUNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&s->h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+  for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
+  for (rt_scene::FrameSlot& f : s->slots) {
+    HIP_TRY(hipMalloc((void**)&f.d_stats, STAT_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void**)&f.h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&f.begin));
+    HIP_TRY(hipEventCreate(&f.end));
+    HIP_TRY(hipEventCreate(&f.done));
+  }
+  return RT_OK;
 }
 
 static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
@@ -2145,14 +2184,8 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((uint64_t)d->n_triangles > MAX_RUN_FIRST || (uint64_t)d->n_leaves > (1u << 24))
     return fail(RT_ERR_UNSUPPORTED, "too many primitives");  // node byte offsets are 32-bit
 
-  HIP_TRY(hipSetDevice(device));
-  s->device = device;
-  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&s->frame_stream, hipStreamNonBlocking));
-  s->last_stream = s->stream;
-  HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&s->copy_order, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&s->copy_order2, hipEventDisableTiming));
+  int rci = scene_runtime_init(s, device);
+  if (rci) return rci;
 
   // ---- acceleration structure
   auto t0 = std::chrono::steady_clock::now();
@@ -2330,11 +2363,11 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     s->dev.band_start = d_start;
     s->dev.band_items = d_items;
     if (d_start) {
-      s->allocs.push_back(d_start);
+      s->allocs.push_back(rt_scene::Alloc{d_start, ((size_t)3 * n * n + 1) * 4, offsetof(SceneDev, band_start)});
       s->scene_bytes += ((size_t)3 * n * n + 1) * 4;
     }
     if (d_items) {
-      s->allocs.push_back(d_items);
+      s->allocs.push_back(rt_scene::Alloc{d_items, (n_items + 1) * 4, offsetof(SceneDev, band_items)});
       s->scene_bytes += n_items * 4;
     }
     if (getenv("RT_AMD_DEBUG"))
@@ -2371,18 +2404,6 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
     s->dev.light_position[a] = d->light.position[a];
   }
 
-  HIP_TRY(hipMalloc((void**)&s->d_counts, COUNT_WORDS * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc((void**)&s->d_stats, STAT_WORDS * sizeof(unsigned long long)));
-  HIP_TRY(hipHostMalloc((void**)&s->h_counts, COUNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void**)&s->h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
-  for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
-  for (rt_scene::FrameSlot& f : s->slots) {
-    HIP_TRY(hipMalloc((void**)&f.d_stats, STAT_WORDS * sizeof(unsigned long long)));
-    HIP_TRY(hipHostMalloc((void**)&f.h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
-    HIP_TRY(hipEventCreate(&f.begin));
-    HIP_TRY(hipEventCreate(&f.end));
-    HIP_TRY(hipEventCreate(&f.done));
-  }
   return RT_OK;
 }
 
@@ -2401,6 +2422,45 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   } catch (const std::exception& e) {
     rc = fail(RT_ERR_INVALID, e.what());
   }
+  if (rc != RT_OK) {
+    std::string keep = g_last_error;
+    rt_scene_destroy(s);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = s;
+  return RT_OK;
+}
+
+// A second copy of a scene on another GPU (or the same one): the acceleration structure is built once
+// and its arrays are copied device to device.
+extern "C" int rt_scene_clone(const rt_scene* src, int device, rt_scene** out) {
+  if (!src || !out) return fail(RT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  rt_scene* s = new (std::nothrow) rt_scene();
+  if (!s) return fail(RT_ERR_NOMEM, "out of host memory");
+  auto work = [&]() -> int {
+    int rc = scene_runtime_init(s, device);
+    if (rc) return rc;
+    s->dev = src->dev;
+    for (const rt_scene::Alloc& a : src->allocs) *(const void**)((char*)&s->dev + a.field) = nullptr;
+    for (const rt_scene::Alloc& a : src->allocs) {
+      void* p = nullptr;
+      HIP_TRY(hipMalloc(&p, a.bytes));
+      s->allocs.push_back(rt_scene::Alloc{p, a.bytes, a.field});
+      HIP_TRY(hipMemcpyPeer(p, device, a.p, src->device, a.bytes));
+      *(const void**)((char*)&s->dev + a.field) = p;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    s->scene_bytes = src->scene_bytes;
+    s->build_seconds = 0;
+    s->stack_need = src->stack_need;
+    s->has_csg = src->has_csg;
+    s->uniform_nodes = src->uniform_nodes;
+    s->max_children = src->max_children;
+    return RT_OK;
+  };
+  int rc = work();
   if (rc != RT_OK) {
     std::string keep = g_last_error;
     rt_scene_destroy(s);
@@ -2539,6 +2599,33 @@ extern "C" int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int
     }
   }
   return missing;
+}
+
+extern "C" int rt_device_alloc(int device, uint64_t bytes, void** out) {
+  if (!out) return fail(RT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int previous = -1;
+  HIP_TRY(hipGetDevice(&previous));
+  HIP_TRY(hipSetDevice(device));
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+  (void)hipSetDevice(previous);
+  if (e != hipSuccess) {
+    if (p) (void)hipFree(p);
+    return fail(e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, std::string("rt_device_alloc: ") + hipGetErrorString(e));
+  }
+  *out = p;
+  return RT_OK;
+}
+
+extern "C" void rt_device_free(int device, void* p) {
+  if (!p) return;
+  int previous = -1;
+  (void)hipGetDevice(&previous);
+  (void)hipSetDevice(device);
+  (void)hipFree(p);
+  if (previous >= 0) (void)hipSetDevice(previous);
 }
 
 extern "C" void* rt_host_alloc(uint64_t bytes) {
@@ -3038,9 +3125,16 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   int rc = collect_all(s);  // frames still in flight finish first
   if (rc) return rc;
   s->last_stream = s->stream;
-  rc = run_pipeline(s, in, stats);
+  rt_stats local{};
+  const bool deferred = (flags & RT_FLAG_ASYNC) != 0;  // asked to enqueue, but this scene's frames need the host
+  rc = run_pipeline(s, in, deferred ? &local : stats);
   if (rc) return rc;
-  if (stats) {
+  if (deferred) {  // reported by rt_scene_wait like the frames that were only enqueued
+    rt_stats& t = s->async_total;
+    t.primary += valid;
+    t.shadow += local.shadow; t.reflect += local.reflect; t.refract += local.refract;
+    t.kernel_ms += local.kernel_ms; t.kernel_launches += local.kernel_launches; t.generations += local.generations;
+  } else if (stats) {
     stats->primary = valid;
     stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   }
@@ -3106,6 +3200,22 @@ extern "C" int rt_download(rt_scene* s, const void* src_dev, void* dst_host, uin
   // a plain asynchronous copy: the runtime moves it with a DMA engine, which leaves the compute units
   // to the frame that renders meanwhile (a copy kernel of our own measured 40 % slower frames)
   HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s->copy_stream));
+  return RT_OK;
+}
+
+extern "C" int rt_copy_fence(rt_scene* s, uint32_t slot) {
+  if (!s || slot >= (uint32_t)rt_scene::COPY_FENCES) return fail(RT_ERR_INVALID, "rt_copy_fence: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventRecord(s->copy_fence[slot], s->copy_stream));
+  s->copy_fence_set[slot] = true;
+  return RT_OK;
+}
+
+extern "C" int rt_copy_wait(rt_scene* s, uint32_t slot) {
+  if (!s || slot >= (uint32_t)rt_scene::COPY_FENCES) return fail(RT_ERR_INVALID, "rt_copy_wait: bad argument");
+  if (!s->copy_fence_set[slot]) return RT_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->copy_fence[slot]));
   return RT_OK;
 }
 

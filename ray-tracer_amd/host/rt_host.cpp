@@ -2,6 +2,9 @@
 // reference file:line (paths relative to the reference crate).
 #include "rt_host.hpp"
 
+#include <condition_variable>
+#include <mutex>
+
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -1120,6 +1123,170 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
   lap("file write", t);
   printf("...done.\n\n");
   printf("Saved render to \"%s\".\n", out_path.c_str());
+}
+
+// ===========================================================================
+// FrameLoop: parallel_render's workers over many frames
+// ===========================================================================
+namespace {
+
+// All workers leave together; reusable.
+class Rendezvous {
+ public:
+  explicit Rendezvous(size_t n) : n_(n) {}
+  void arrive_and_wait() {
+    std::unique_lock<std::mutex> lock(m_);
+    const size_t round = round_;
+    if (++here_ == n_) {
+      here_ = 0;
+      round_++;
+      cv_.notify_all();
+    } else {
+      cv_.wait(lock, [&] { return round_ != round; });
+    }
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  size_t n_, here_ = 0, round_ = 0;
+};
+
+void check_rt(int rc) {
+  if (rc != RT_OK) throw std::runtime_error(rt_last_error());
+}
+
+}  // namespace
+
+FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth)
+    : devices_(devices), depth_(depth) {
+  if (devices.empty()) throw Panic("assertion failed: size > 0");  // src/parallel.rs:94
+  if (depth < 1 || depth > 8) throw std::invalid_argument("FrameLoop: depth must lie in 1..8");
+  cam_ = camera.describe();
+  frame_bytes_ = (size_t)cam_.hsize * cam_.vsize * 3;
+  if (frame_bytes_ == 0) throw std::invalid_argument("FrameLoop: empty canvas");
+  try {
+    FlatWorld flat = flatten(world);
+    rt_scene_desc desc = flat.desc();
+    scenes_.assign(devices.size(), nullptr);
+    check_rt(rt_scene_create(&desc, devices[0], &scenes_[0]));
+    check_rt(rt_scene_footprint(scenes_[0], nullptr, &build_seconds_));
+    for (size_t k = 1; k < devices.size(); k++) check_rt(rt_scene_clone(scenes_[0], devices[k], &scenes_[k]));
+    for (int k = 0; k < depth; k++) {
+      uint8_t* p = (uint8_t*)rt_host_alloc(frame_bytes_);
+      if (!p) throw std::runtime_error("FrameLoop: no page-locked host memory for the frame ring");
+      host_.push_back(p);
+    }
+    dev_frames_.resize(devices.size());
+    for (size_t k = 0; k < devices.size(); k++)
+      for (int j = 0; j < depth; j++) {
+        void* p = nullptr;
+        check_rt(rt_device_alloc(devices[k], frame_bytes_, &p));
+        dev_frames_[k].push_back((uint8_t*)p);
+      }
+  } catch (...) {
+    release();
+    throw;
+  }
+}
+
+void FrameLoop::release() {
+  for (size_t k = 0; k < dev_frames_.size(); k++)
+    for (uint8_t* p : dev_frames_[k]) rt_device_free(devices_[k], p);
+  dev_frames_.clear();
+  for (rt_scene* s : scenes_) rt_scene_destroy(s);
+  scenes_.clear();
+  for (uint8_t* p : host_) rt_host_free(p);
+  host_.clear();
+}
+
+FrameLoop::~FrameLoop() { release(); }
+
+uint64_t FrameLoop::scene_bytes() const {
+  uint64_t b = 0;
+  if (!scenes_.empty()) (void)rt_scene_footprint(scenes_[0], &b, nullptr);
+  return b;
+}
+
+FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
+  const size_t n = scenes_.size();
+  Result result;
+  result.part.assign(n, rt_stats{});
+  std::vector<std::string> errors(n);
+  Rendezvous meet(n);
+  std::chrono::steady_clock::time_point t0, t1;
+  const size_t w = cam_.hsize, rows_total = cam_.vsize, band_bytes = (size_t)32 * w * 3;
+  auto worker = [&](size_t k) {
+    rt_scene* sc = scenes_[k];
+    bool ok = true;
+    auto frame = [&](size_t f) {
+      if (!ok) return;
+      const int slot = (int)(f % (size_t)depth_);
+      uint8_t* dev = dev_frames_[k][(size_t)slot];
+      // the copy that last read this device frame (depth frames ago) must be through before it is rendered over
+      if (to_host && rt_copy_wait(sc, (uint32_t)slot) != RT_OK) ok = false;
+      if (ok && rt_render(sc, &cam_, (int)k, (int)n, RT_FLAG_ASYNC | RT_FLAG_BANDS, dev, nullptr, nullptr, nullptr) != RT_OK) ok = false;
+      if (ok && to_host && n == 1) {  // the whole frame is this part's: one contiguous copy
+        if (rt_download(sc, dev, host_[(size_t)slot], frame_bytes_, nullptr) != RT_OK) ok = false;
+        if (ok && rt_copy_fence(sc, (uint32_t)slot) != RT_OK) ok = false;
+      } else if (ok && to_host) {
+        // this part's bands: whole bands with one strided copy, a last partial band with a plain one
+        const size_t first = k * 32, n_bands_mine = first < rows_total ? (rows_total - first + n * 32 - 1) / (n * 32) : 0;
+        size_t whole = n_bands_mine;
+        if (n_bands_mine && first + (n_bands_mine - 1) * n * 32 + 32 > rows_total) whole--;
+        uint8_t* host = host_[(size_t)slot];
+        const size_t off = first * w * 3;
+        if (whole && rt_download_2d(sc, dev + off, host + off, band_bytes, whole, n * band_bytes, nullptr) != RT_OK) ok = false;
+        if (ok && whole != n_bands_mine) {
+          const size_t y0 = first + whole * n * 32, o = y0 * w * 3;
+          if (rt_download(sc, dev + o, host + o, (rows_total - y0) * w * 3, nullptr) != RT_OK) ok = false;
+        }
+        if (ok && rt_copy_fence(sc, (uint32_t)slot) != RT_OK) ok = false;
+      }
+      if (!ok) errors[k] = rt_last_error();
+    };
+    for (size_t f = 0; f < warmup; f++) frame(f);
+    rt_stats st{};
+    if (ok && rt_scene_wait(sc, &st) != RT_OK) {
+      ok = false;
+      errors[k] = rt_last_error();
+    }
+    meet.arrive_and_wait();  // every GPU idle, every worker ready
+    if (k == 0) t0 = std::chrono::steady_clock::now();
+    for (size_t f = 0; f < frames; f++) frame(warmup + f);
+    if (ok && rt_scene_wait(sc, &result.part[k]) != RT_OK) {  // rendered and, with to_host, on the host
+      ok = false;
+      errors[k] = rt_last_error();
+    }
+    meet.arrive_and_wait();
+    if (k == 0) t1 = std::chrono::steady_clock::now();
+  };
+  std::vector<std::thread> threads;
+  for (size_t k = 1; k < n; k++) threads.emplace_back(worker, k);
+  worker(0);
+  for (auto& t : threads) t.join();
+  for (const std::string& e : errors)
+    if (!e.empty()) throw std::runtime_error(e);
+  result.seconds = std::chrono::duration<double>(t1 - t0).count();
+  return result;
+}
+
+std::vector<rt_stats> FrameLoop::blocking_frames(size_t frames, bool counters) {
+  std::vector<rt_stats> out(scenes_.size(), rt_stats{});
+  for (size_t f = 0; f < frames; f++)
+    for (size_t k = 0; k < scenes_.size(); k++) {
+      rt_stats st{};
+      check_rt(rt_render(scenes_[k], &cam_, (int)k, (int)scenes_.size(), (counters ? RT_FLAG_COUNTERS : 0u) | RT_FLAG_BANDS,
+                         dev_frames_[k][0], nullptr, nullptr, &st));
+      rt_stats& o = out[k];
+      o.primary += st.primary; o.shadow += st.shadow; o.reflect += st.reflect; o.refract += st.refract;
+      o.render_ms += st.render_ms; o.kernel_ms += st.kernel_ms;
+      o.kernel_launches += st.kernel_launches; o.generations += st.generations;
+      o.node_visits += st.node_visits; o.tri_tests += st.tri_tests; o.quadric_tests += st.quadric_tests; o.gate_tests += st.gate_tests;
+      o.shadow_node_visits += st.shadow_node_visits; o.shadow_tri_tests += st.shadow_tri_tests;
+      o.shadow_quadric_tests += st.shadow_quadric_tests; o.shadow_gate_tests += st.shadow_gate_tests;
+    }
+  return out;
 }
 
 }  // namespace rthost

@@ -131,4 +131,48 @@ Canvas render_canvas(const World& world, const Camera& camera, size_t jobs);
 // parallel_render (src/parallel.rs:183-204): `jobs` is the number of GPUs.
 void parallel_render(const World& world, const Camera& camera, size_t jobs, const std::string& out_path);
 
+
+// parallel_render's workers kept alive over many frames (the reference renders one frame per process,
+// src/main.rs:71; a viewer or a camera sweep renders many).  One worker thread and one copy of the scene
+// per part; part k renders the bands of 32 pixel rows k, k + parts, ... on device devices[k] and copies
+// exactly those bands over that GPU's own link into a host frame all workers share, so a frame is
+// complete when every worker has passed it and no GPU-to-GPU exchange takes place.  The acceleration
+// structure is built once (rt_scene_create on the first device, rt_scene_clone for the others).
+class FrameLoop {
+ public:
+  struct Result {
+    double seconds = 0;          // wall time of the timed frames: start barrier -> all workers drained
+    std::vector<rt_stats> part;  // per part: sums over its timed frames (rays by kind, kernel time, launches)
+  };
+  // devices[k]: GPU of part k (the same GPU may serve several parts).  depth: frames in flight per worker
+  // and host frames in the ring (1..8).
+  FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth);
+  ~FrameLoop();
+  FrameLoop(const FrameLoop&) = delete;
+  FrameLoop& operator=(const FrameLoop&) = delete;
+  // `warmup` untimed frames, then `frames` timed ones.  to_host: every frame is copied into the host ring
+  // (frame f into slot f % depth); otherwise frames stay in each GPU's memory.
+  Result run(size_t warmup, size_t frames, bool to_host);
+  // `frames` frames rendered one at a time (each call blocks, nothing overlaps), optionally with the
+  // traversal counters switched on; per part, summed over the frames.
+  std::vector<rt_stats> blocking_frames(size_t frames, bool counters);
+  const uint8_t* host_frame(int slot) const { return host_[(size_t)slot]; }
+  size_t frame_bytes() const { return frame_bytes_; }
+  size_t parts() const { return scenes_.size(); }
+  rt_scene* scene(size_t part) const { return scenes_[part]; }
+  uint64_t scene_bytes() const;
+  double build_seconds() const { return build_seconds_; }
+
+ private:
+  rt_camera cam_{};
+  std::vector<int> devices_;
+  std::vector<rt_scene*> scenes_;
+  std::vector<std::vector<uint8_t*>> dev_frames_;  // [part][slot], on the part's GPU
+  std::vector<uint8_t*> host_;                     // [slot], page-locked, shared by all parts
+  size_t frame_bytes_ = 0;
+  int depth_ = 0;
+  double build_seconds_ = 0;
+  void release();
+};
+
 }  // namespace rthost

@@ -159,6 +159,52 @@ int rth_canvas_save(const rth_canvas* c, const char* path) {
   });
 }
 
+// ---- FrameLoop: one worker and one copy of the scene per part, frames gathered in a shared host ring
+struct rth_frame_loop {
+  std::unique_ptr<FrameLoop> loop;
+};
+
+int rth_frame_loop_new(rth_scene* h, uint64_t parts, const int32_t* devices, int32_t depth, rth_frame_loop** out) {
+  *out = nullptr;
+  return guarded([&]() -> int {
+    std::vector<int> dev(devices, devices + parts);
+    std::unique_ptr<rth_frame_loop> l(new rth_frame_loop());
+    l->loop.reset(new FrameLoop(h->scene.world, h->scene.camera, dev, depth));
+    *out = l.release();
+    return RT_OK;
+  });
+}
+
+void rth_frame_loop_free(rth_frame_loop* l) { delete l; }
+
+// stats: one rt_stats per part.  *seconds: wall time of the timed frames.
+int rth_frame_loop_run(rth_frame_loop* l, uint64_t warmup, uint64_t frames, int32_t to_host, double* seconds, rt_stats* stats) {
+  return guarded([&]() -> int {
+    FrameLoop::Result r = l->loop->run(warmup, frames, to_host != 0);
+    if (seconds) *seconds = r.seconds;
+    if (stats)
+      for (size_t k = 0; k < r.part.size(); k++) stats[k] = r.part[k];
+    return RT_OK;
+  });
+}
+
+int rth_frame_loop_blocking(rth_frame_loop* l, uint64_t frames, int32_t counters, rt_stats* stats) {
+  return guarded([&]() -> int {
+    std::vector<rt_stats> r = l->loop->blocking_frames(frames, counters != 0);
+    for (size_t k = 0; k < r.size(); k++) stats[k] = r[k];
+    return RT_OK;
+  });
+}
+
+const uint8_t* rth_frame_loop_host_frame(rth_frame_loop* l, int32_t slot) { return l->loop->host_frame(slot); }
+
+// out[0] = scene bytes per GPU, out[1] = frame bytes; *build_seconds: the one build of the acceleration structure
+void rth_frame_loop_info(rth_frame_loop* l, uint64_t* out, double* build_seconds) {
+  out[0] = l->loop->scene_bytes();
+  out[1] = l->loop->frame_bytes();
+  if (build_seconds) *build_seconds = l->loop->build_seconds();
+}
+
 uint64_t rth_ppm_encode(uint64_t w, uint64_t hh, const uint8_t* rgb8, char* buf, uint64_t cap) {
   std::string s = ppm_encode(w, hh, rgb8);
   if (buf && cap) memcpy(buf, s.data(), s.size() < cap ? s.size() : cap);

@@ -1,0 +1,76 @@
+"""The many-frame form of parallel_render (src/parallel.rs:183-204): one worker and one scene copy per
+part, every part copying its own bands of 32 pixel rows into one shared host frame.  On the one GPU of
+the test box all parts run on device 0; the frame must equal the frame one part renders, byte for byte."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,size", [("teapot", (200, 150)), ("glass", (161, 97)), ("example", (64, 32))])
+def test_parts_fill_one_host_frame(pkg, root, name, size):
+    path = os.path.join(root, "scenes", name + ".json")
+    whole = pkg.Scene.from_file(path, base_dir=root, device=0)
+    whole.set_canvas(*size)
+    want = whole.render(rgb64=False, hit_leaf=False)[0]["rgb8"]
+    host = pkg.Scene.from_file(path, base_dir=root, device=None)  # the loop owns its GPU copies
+    host.set_canvas(*size)
+    for parts in (1, 2, 3, 7):  # 150 rows = 4 whole bands and one of 22 rows; 7 parts: some own nothing
+        loop = host.frame_loop([0] * parts, depth=3)
+        seconds, stats = loop.run(2, 5, True)
+        assert seconds > 0 and len(stats) == parts
+        assert sum(s.primary for s in stats) == 5 * size[0] * size[1]
+        for slot in range(3):
+            assert np.array_equal(loop.host_frame(slot), want), "parts=%d slot=%d" % (parts, slot)
+        counted = loop.blocking_frames(1, counters=True)
+        assert sum(s.primary for s in counted) == size[0] * size[1]
+        assert sum(s.node_visits + s.quadric_tests for s in counted) > 0
+        loop.close()
+
+
+def test_clone_renders_the_same_frame(pkg, root):
+    import ctypes as C
+    amd, _ = pkg.bindings.libraries()
+    scene = pkg.Scene.from_file(os.path.join(root, "scenes", "glass.json"), base_dir=root, device=0)
+    scene.set_canvas(120, 80)
+    want, _ = scene.render()
+    twin = C.c_void_p()
+    assert amd.rt_scene_clone(scene._dev(), 0, C.byref(twin)) == 0
+    cam = scene.camera()
+    a8 = np.zeros((80, 120, 3), np.uint8)
+    a64 = np.zeros((80, 120, 3), np.float64)
+    leaf = np.full((80, 120), -1, np.int32)
+    st = pkg.bindings.RtStats()
+    rc = amd.rt_render_host(twin, C.byref(cam), 0, 1, 0, a8.ctypes.data_as(C.c_void_p), a64.ctypes.data_as(C.c_void_p),
+                            leaf.ctypes.data_as(C.c_void_p), C.byref(st))
+    amd.rt_scene_destroy.argtypes = [C.c_void_p]
+    amd.rt_scene_destroy(twin)
+    assert rc == 0
+    assert np.array_equal(a8, want["rgb8"]) and np.array_equal(leaf, want["hit_leaf"])
+    assert np.array_equal(a64, want["rgb64"])
+
+
+def run_bench(root, *flags):
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-hbm-leg", *flags],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_runs_bare_with_two_gpus_requested(root):
+    """`python bench.py --gpus 2` as a plain child process (no launcher): rc 0, n_gpus 2, and the gathered
+    frame equals the frame of the one-GPU run."""
+    one = run_bench(root, "--gpus", "1", "--steps", "2", "--warmup", "1")
+    two = run_bench(root, "--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["devices"] in ([0, 1], [0, 0])
+    assert one["frame_sha256"] == two["frame_sha256"]
+    assert one["config"]["rays_per_frame"] == two["config"]["rays_per_frame"]
+    for line in (one, two):
+        assert line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
+        assert line["roofline"]["frac"] > 0 and line["roofline"]["launches_per_frame"] == line["n_gpus"]

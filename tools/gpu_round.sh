@@ -1,22 +1,37 @@
 #!/bin/bash
-# One GPU session: smoke, bench, rocprofv3 kernel trace, HBM-traffic counter passes.  Every GPU step
-# runs under its own time limit and the steps are chained, so trouble ends the script.
+# One GPU session: smoke, bench, rocprofv3 kernel trace (stats + timeline), counter passes.  Every GPU
+# step runs under its own time limit and the steps are chained, so trouble ends the script.
+# usage: tools/gpu_round.sh <tag>      results under gpurun_out/<tag>/
 set -o pipefail
-mkdir -p gpurun_out
+tag=${1:-round}
+O=gpurun_out/$tag
+rm -rf $O && mkdir -p $O
 export TMPDIR=/tmp
-timeout -k 10 200 python -u -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 || { echo "smoke failed"; tail -20 gpurun_out/smoke.log; exit 1; }
-tail -2 gpurun_out/smoke.log
-timeout -k 10 300 python -u bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err || { echo "bench failed"; tail -20 gpurun_out/bench.err; exit 1; }
-cat gpurun_out/bench.json
-rm -rf gpurun_out/prof gpurun_out/pmc_traffic
-# the headline leg alone (frames stay in HBM): every k_generation launch in the table belongs to the loop whose
-# launches bench.py times with HIP events, so the two averages are comparable
-rm -rf gpurun_out/prof_nocopy
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_nocopy -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-download > gpurun_out/prof_nocopy_bench.json 2> gpurun_out/prof_nocopy.err || { echo "rocprof (no copy) failed"; tail -20 gpurun_out/prof_nocopy.err; exit 1; }
-find gpurun_out/prof_nocopy -name "*kernel_stats*.csv" | head -3
-# both legs; rocprofv3 turns the host copies of the second leg into copy kernels that stretch the render kernel
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err || { echo "rocprof failed"; tail -20 gpurun_out/prof.err; exit 1; }
-mkdir -p gpurun_out/pmc_traffic
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_traffic/p1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-download > gpurun_out/pmc_traffic/p1.out 2> gpurun_out/pmc_traffic/p1.err || { echo "FETCH_SIZE pass failed"; tail -5 gpurun_out/pmc_traffic/p1.err; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_traffic/p2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-download > gpurun_out/pmc_traffic/p2.out 2> gpurun_out/pmc_traffic/p2.err || { echo "WRITE_SIZE pass failed"; tail -5 gpurun_out/pmc_traffic/p2.err; exit 1; }
-python3 tools/traffic_json.py gpurun_out/pmc_traffic gpurun_out/traffic.json
+B="--steps 20 --warmup 5"  # 64 priming + 5 warm-up launches precede the 20 timed ones: launches 69..88
+timeout -k 10 200 python -u -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { echo "smoke failed"; tail -20 $O/smoke.log; exit 1; }
+tail -1 $O/smoke.log
+timeout -k 10 300 python -u bench.py $B > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -20 $O/bench.err; exit 1; }
+# the loop that leaves the frames in HBM, alone: under rocprofv3 the runtime turns the DMA copies of the metric's
+# loop into copy kernels that share the GPU with the render kernel, so that loop is traced separately below
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_hbm -- python3 bench.py $B --no-cpu-baseline --hbm-only > $O/trace_hbm_bench.json 2> $O/trace_hbm.err || { echo "rocprof (hbm) failed"; tail -20 $O/trace_hbm.err; exit 1; }
+python3 tools/timeline.py $O/trace_hbm 69 20 > $O/timeline_hbm.txt || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_host -- python3 bench.py $B --no-cpu-baseline --no-hbm-leg > $O/trace_host_bench.json 2> $O/trace_host.err || { echo "rocprof (host) failed"; tail -20 $O/trace_host.err; exit 1; }
+python3 tools/timeline.py $O/trace_host 69 20 > $O/timeline_host.txt || exit 1
+P="--steps 3 --warmup 1 --no-cpu-baseline --hbm-only"
+pass() {  # name, counters
+  timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $O/pmc/$1 -- python3 bench.py $P > $O/pmc_$1.out 2> $O/pmc_$1.err || { echo "pmc pass $1 failed"; tail -5 $O/pmc_$1.err; exit 1; }
+}
+mkdir -p $O/pmc
+pass fetch "FETCH_SIZE" && pass write "WRITE_SIZE" && \
+pass f64 "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" && \
+pass wait "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE" && \
+pass cache "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" && \
+pass tatd "TA_TA_BUSY_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE" || exit 1
+mkdir -p $O/pmc_traffic && cp -r $O/pmc/fetch $O/pmc_traffic/p1 && cp -r $O/pmc/write $O/pmc_traffic/p2
+python3 tools/traffic_json.py $O/pmc_traffic $O/traffic.json > /dev/null || exit 1
+python3 tools/pmc_f64_json.py $O/pmc $O/pmc_f64.json > /dev/null || exit 1
+python3 tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt || exit 1
+for t in trace_hbm trace_host; do f=$(find $O/$t -name "*kernel_stats.csv" -print -quit); [ -n "$f" ] && cp "$f" $O/${t}_kernel_stats.csv; done
+# keep the merged output small: the raw traces and counter CSVs stay on the box
+rm -rf $O/trace_hbm $O/trace_host $O/pmc $O/pmc_traffic
+ls $O
