@@ -101,3 +101,19 @@ def test_blend_pattern_through_a_hand_built_description(pkg, root):
     bad.second = 7
     patterns[2] = bad
     assert amd.rt_scene_create(C.byref(desc), 0, C.byref(scene)) == -1 and b"blend" in amd.rt_last_error()
+
+
+def test_plain_c_program_renders_the_example_scene(pkg, root, tmp_path):
+    """tests/abi_smoke.c (C99, built by the Makefile): create -> render -> destroy on example.json's two
+    shapes flattened by hand; its frame must equal the one the host library's loader and flattener give."""
+    import subprocess
+    scene = pkg.Scene.from_file(os.path.join(root, "scenes", "example.json"), base_dir=root, device=0)
+    scene.set_canvas(96, 54)
+    want = scene.render(rgb64=False, hit_leaf=False)[0]["rgb8"]
+    cam = scene.camera()
+    (tmp_path / "camera.bin").write_bytes(bytes(cam))
+    exe = os.path.join(root, "ray-tracer_amd", "lib", "abi_smoke")
+    p = subprocess.run([exe, str(tmp_path / "camera.bin"), str(tmp_path / "out.rgb8")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    got = np.frombuffer((tmp_path / "out.rgb8").read_bytes(), np.uint8).reshape(54, 96, 3)
+    assert np.array_equal(got, want)

@@ -23,6 +23,18 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(host, n)
 
 
+def test_header_is_plain_c99(tmp_path):
+    """include/rt_amd.h compiles as C99 with no extensions; the smoke program that uses it was built the same way."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "rt_amd.h"\nint main(void) { rt_scene_desc d; rt_camera c; (void)d; (void)c; return (int)sizeof(rt_stats) - 128; }\n')
+    exe = tmp_path / "use_header"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+    assert os.path.exists(os.path.join(ROOT, "ray-tracer_amd", "lib", "abi_smoke"))
+
+
 def test_struct_layouts_match_the_header(pkg):
     assert ctypes.sizeof(pkg.RtCamera) == 8 + 3 * 8 + 16 * 8
     assert ctypes.sizeof(pkg.RtStats) == 4 * 8 + 2 * 8 + 2 * 8 + 8 * 8
