@@ -22,6 +22,28 @@ import scenegen  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 
 
+FP64_VALU_PEAK, HBM_PEAK = 78.6e12, 8.0e12
+SURVEY = {"node": 22, "tri": 46, "quad": 60, "hit": 150}  # flops per event, the measurement plan's coefficients
+WARM = 8
+
+
+def roofline(c, kernel_ms, scene_bytes):
+    """Events of one instrumented frame priced with the plan's coefficients, and the HBM bytes the
+    algorithm cannot avoid (scene once per generation, 3 B per pixel, 120 B written and read back per
+    recorded ray), against the generation kernels' time of one frame."""
+    nv, tt = c.node_visits + c.shadow_node_visits, c.tri_tests + c.shadow_tri_tests
+    qt, gt = c.quadric_tests + c.shadow_quadric_tests, c.gate_tests + c.shadow_gate_tests
+    flops = nv * SURVEY["node"] + tt * SURVEY["tri"] + qt * SURVEY["quad"] + c.shadow * SURVEY["hit"]
+    secondary = c.reflect + c.refract
+    records = (c.primary if secondary else 0) + secondary
+    hbm = c.kernel_launches * scene_bytes + c.primary * 3 + 2 * records * 120
+    t = kernel_ms * 1e-3
+    return {"events": {"node_visits": nv, "tri_tests": tt, "quadric_tests": qt, "gate_tests": gt, "shaded_hits": c.shadow},
+            "flops_per_frame": flops, "unavoidable_hbm_bytes_per_frame": hbm, "kernel_ms_per_frame": kernel_ms,
+            "frac_fp64_valu": flops / t / FP64_VALU_PEAK, "frac_hbm_unavoidable": hbm / t / HBM_PEAK,
+            "launches_per_frame": c.kernel_launches}
+
+
 def run(pkg, name, path, size, frames, cameras=None, counters=False):
     t0 = time.perf_counter()
     scene = pkg.Scene.from_file(path, base_dir=ROOT, device=0)
@@ -31,7 +53,7 @@ def run(pkg, name, path, size, frames, cameras=None, counters=False):
     info, foot = scene.info(), scene.footprint()
     w, h = info["width"], info["height"]
     frame = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
-    for k in range(8):  # first touches of freshly allocated ray queues, clocks
+    for k in range(WARM):  # first touches of freshly allocated ray queues, clocks
         scene.render_device(rgb8_ptr=frame.data_ptr())
     torch.cuda.synchronize()
     kernel_ms = render_ms = 0.0
@@ -52,6 +74,7 @@ def run(pkg, name, path, size, frames, cameras=None, counters=False):
            "scene_MB": foot["scene_bytes"] / 1e6, "bvh_build_s": foot["build_seconds"], "load_s": load_s}
     if counters:
         c = scene.render_device(rgb8_ptr=frame.data_ptr(), counters=True)
+        out["roofline"] = roofline(c, kernel_ms / frames, foot["scene_bytes"])
         out["per_ray"] = {"node_visits": (c.node_visits + c.shadow_node_visits) / c.rays,
                           "tri_tests": (c.tri_tests + c.shadow_tri_tests) / c.rays,
                           "quadric_tests": (c.quadric_tests + c.shadow_quadric_tests) / c.rays,
@@ -66,7 +89,10 @@ def main():
     ap.add_argument("--sweep-frames", type=int, default=60)
     ap.add_argument("--only", default="")
     ap.add_argument("--counters", action="store_true")
+    ap.add_argument("--warm", type=int, default=8, help="untimed frames before the timed ones")
     args = ap.parse_args()
+    global WARM
+    WARM = args.warm
     pkg = load_package()
     want = set(args.only.split(",")) if args.only else None
 
