@@ -148,6 +148,8 @@ struct Counters {
 #endif
 };
 #ifdef RT_STAMPS
+// one count per wave and loop iteration (by the first active lane): lane events / (64 x these) = lane utilisation
+#define RT_WAVE_ITER(c, k) do { if ((c).sink && (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd((c).sink + 4 + (k), 1ull); } while (0)
 #define RT_TBEGIN(c) (c).tt = __builtin_amdgcn_s_memtime()
 #define RT_TSTAMP(c, k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
     if ((c).sink && (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd((c).sink + (k), now_ - (c).tt); \
@@ -155,6 +157,7 @@ struct Counters {
 #else
 #define RT_TBEGIN(c) do { } while (0)
 #define RT_TSTAMP(c, k) do { } while (0)
+#define RT_WAVE_ITER(c, k) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -497,12 +500,13 @@ struct LdsStack {
 // near plane of an axis is the lower one when the direction is positive.  Only t >= 0 matters
 // (queries behind the origin walk the reversed ray), so a test stays conservative when every near
 // value is computed too small and every far value too large:
-//   inv          1 / direction from v_rcp_f32 (relative error below 2^-22); origin * inv is formed
-//                with that same inv, so the error of inv only scales t
-//   near / far   inv and origin * inv scaled by (1 -/+ 2^-20), which covers the error of inv and the
-//                rounding of the fused multiply-add (2^-24 |t| each)
-//   c_n / c_f    additionally moved by 2^-22 |origin * inv| and rounded outward: covers the f32
-//                rounding of inv and of origin * inv, which are relative to |origin * inv|, not to t
+//   inv          1 / direction from v_rcp_f32 on the direction rounded to f32 (relative error below
+//                2^-22); origin * inv is formed with that same inv, so the error of inv only scales t
+//   near / far   inv and origin * inv scaled by (1 -/+ 1.5e-6), which covers the error of inv, the
+//                rounding of the scaled values and that of the box test's multiply-add (2^-24 |t| each)
+//   c_n / c_f    additionally moved outward by 1e-6 |origin * inv|: covers the f32 roundings of the
+//                origin, of origin * inv and of the scaled value, which are relative to
+//                |origin * inv|, not to t (2^-24 each, 2^-22 in all)
 // A box test can therefore pass wrongly but never fail wrongly.
 struct RayBox {
   float inv_n[3], c_n[3], inv_f[3], c_f[3];
@@ -516,18 +520,23 @@ DEV RayBox make_raybox(const Ray& r, bool reversed) {
   b.tiny = false;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    double dir = reversed ? -d[a] : d[a];
+    const double dir = reversed ? -d[a] : d[a];
     if (fabs(dir) < FEQ_EPSILON) b.tiny = true;
-    if (!(fabs(dir) >= 1e-20)) dir = copysign(1e-20, dir);  // parallel: a huge finite slope, no inf * 0
-    double inv = (double)__builtin_amdgcn_rcpf((float)dir);
-    double oinv = o[a] * inv;
-    double slack = fabs(oinv) * 2.4e-7 + 1e-30;
-    const double lo_s = 1.0 - 9.6e-7, hi_s = 1.0 + 9.6e-7;
-    b.inv_n[a] = (float)(inv * lo_s);
-    b.inv_f[a] = (float)(inv * hi_s);
-    b.c_n[a] = __double2float_ru(oinv * lo_s + slack);
-    b.c_f[a] = __double2float_rd(oinv * hi_s - slack);
-    b.off_near[a] = 32u * a + (inv < 0.0 ? 16u : 0u);
+    float dirf = (float)dir;
+    if (!(fabsf(dirf) >= 1e-20f)) dirf = copysignf(1e-20f, dirf);  // parallel: a huge finite slope, no inf * 0
+    // Everything below in single precision.  inv is within 2^-22 of 1 / direction (rounding of the
+    // direction, v_rcp_f32), oinv within 2^-22 |oinv| of origin / direction (rounding of the origin,
+    // of inv, of the product); scaling by (1 -/+ 1.5e-6) covers the first and the roundings of the
+    // scaled values and of the box test's multiply-add, the slack of 1e-6 |oinv| the second.
+    const float inv = __builtin_amdgcn_rcpf(dirf);
+    const float oinv = (float)o[a] * inv;
+    const float slack = fabsf(oinv) * 1e-6f + 1e-30f;
+    const float lo_s = 1.0f - 1.5e-6f, hi_s = 1.0f + 1.5e-6f;
+    b.inv_n[a] = inv * lo_s;
+    b.inv_f[a] = inv * hi_s;
+    b.c_n[a] = fmaf(oinv, lo_s, slack);
+    b.c_f[a] = fmaf(oinv, hi_s, -slack);
+    b.off_near[a] = 32u * a + (inv < 0.0f ? 16u : 0u);
   }
   return b;
 }
@@ -701,6 +710,19 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
 template <class Query, class Stack, bool COUNT>
 DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counters& cnt) {
   RT_TBEGIN(cnt);
+#pragma unroll
+  for (int i = 0; i < MAX_INLINE_PLANES; i++) {
+    if (i < S.n_inline_planes) {  // intersect_plane (src/shape.rs:891-908) on the y row of the transformed ray
+      const InlinePlane& P = S.inline_planes[i];
+      if (COUNT) cnt.quad_tests++;
+      const double oy = P.row[0] * ray.o.x + P.row[1] * ray.o.y + P.row[2] * ray.o.z + P.row[3];
+      const double dy = P.row[0] * ray.d.x + P.row[1] * ray.d.y + P.row[2] * ray.d.z;
+      if (!(fabs(dy) <= FEQ_EPSILON)) {
+        double t[1] = {-oy / dy};
+        Q.leaf_ts(P.leaf, 1, t);
+      }
+    }
+  }
   for (int i = 0; i < S.n_unbounded; i++) {
     if (COUNT) cnt.quad_tests++;
     test_quad<Query, Stack::WITH_CSG>(S, S.unbounded[i], ray, Q, true);
@@ -798,6 +820,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     while ((cur >> 30) == KIND_INNER) {
       const uint32_t nd = cur << 7;  // byte offset of the node (inner kind bits are zero)
       if (COUNT) cnt.node_visits++;
+      RT_WAVE_ITER(cnt, 0);
       float tn[4];
       uint32_t c[4];
       bool together = false;
@@ -840,6 +863,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       cur = bc != REF_NONE ? bc : st.pop_or_none();
     }
     RT_TSTAMP(cnt, 1);
+    RT_WAVE_ITER(cnt, 3);  // rounds of the outer loop
     if (cur == REF_NONE) break;
     const uint32_t kind = cur >> 30;
     if (kind == KIND_GATE) {
@@ -868,6 +892,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       for (uint32_t i = 0; i < count; i++) {
         const TriIsect& tr = S.tris[first + i];
         if (COUNT) cnt.tri_tests++;
+        RT_WAVE_ITER(cnt, 1);
         double t, u, v;
         bool hit;
         if (tr.xform >= 0) {
@@ -882,6 +907,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     } else {
       for (uint32_t i = 0; i < count; i++) {
         if (COUNT) cnt.quad_tests++;
+        RT_WAVE_ITER(cnt, 2);
         test_quad<Query, Stack::WITH_CSG>(S, S.quads[first + i], ray, Q, false);
       }
       RT_TSTAMP(cnt, 3);
@@ -942,7 +968,7 @@ constexpr int COUNT_WORDS = (MAX_GENERATIONS + 1) * QUEUE_SEGMENTS;  // queue co
 constexpr int STAT_RAYS = 8;
 #ifdef RT_STAMPS
 // Diagnostic build: per-wave clock stamps between the sections of k_generation, summed per section.
-constexpr int STAMP_WORDS = 16;
+constexpr int STAMP_WORDS = 24;  // 0..4 sections of k_generation, 8..11 / 16..19 closest, 12..15 / 20..23 shadow
 #else
 constexpr int STAMP_WORDS = 0;
 #endif
@@ -958,7 +984,7 @@ constexpr int STAT_WORDS = STAT_RAYS + 3 * STAT_SLOTS + STAMP_WORDS;
 // 64 rays of a wave stay close in screen space.
 DEV bool ray_pixel(const uint32_t* tiles, uint32_t tiles_x, const CameraDev& cam, uint32_t i, uint32_t& x,
                    uint32_t& y) {
-  uint32_t tile = tiles[i / TILE_PIXELS];
+  uint32_t tile = tiles ? tiles[i / TILE_PIXELS] : i / TILE_PIXELS;  // no table: the part owns every tile, in order
   uint32_t in_tile = i % TILE_PIXELS;
   uint32_t wave = in_tile >> 6, lane = in_tile & 63u;
   x = (tile % tiles_x) * TILE + (wave & 3u) * 8u + (lane & 7u);
@@ -1260,8 +1286,8 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
 
   Counters ct{}, cs{};
 #ifdef RT_STAMPS
-  ct.sink = stats + STAT_RAYS + 3 * STAT_SLOTS + 8;
-  cs.sink = stats + STAT_RAYS + 3 * STAT_SLOTS + 12;
+  ct.sink = stats + STAT_RAYS + 3 * STAT_SLOTS + 8;   // time sums at sink[0..3], wave iterations at sink[4..7]:
+  cs.sink = stats + STAT_RAYS + 3 * STAT_SLOTS + 16;  // two blocks of eight
 #endif
   ClosestQuery Q;
   Q.init();
@@ -2317,6 +2343,21 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((rc = upload(s, tris, &s->dev.tris))) return rc;
   if ((rc = upload(s, quads, &s->dev.quads))) return rc;
   if ((rc = upload(s, b.gates, &s->dev.gates))) return rc;
+  // top-level planes without a transform chain go into the kernel arguments (the order among the
+  // shapes tested for every ray does not matter: equal distances resolve by leaf index)
+  s->dev.n_inline_planes = 0;
+  for (size_t i = 0; i < b.unbounded.size();) {
+    const QuadPrim& q = b.unbounded[i];
+    if (q.type == RT_PLANE && q.gate < 0 && s->dev.n_inline_planes < MAX_INLINE_PLANES) {
+      InlinePlane& P = s->dev.inline_planes[s->dev.n_inline_planes++];
+      for (int k = 0; k < 4; k++) P.row[k] = q.m[4 + k];
+      P.leaf = q.leaf;
+      P.pad = 0;
+      b.unbounded.erase(b.unbounded.begin() + (long)i);
+    } else {
+      i++;
+    }
+  }
   if ((rc = upload(s, b.unbounded, &s->dev.unbounded))) return rc;
   if ((rc = upload(s, b.csg_roots, &s->dev.csg_roots))) return rc;
   if ((rc = upload(s, b.csg_nodes, &s->dev.csg_nodes))) return rc;
@@ -2769,7 +2810,9 @@ int collect_frame(rt_scene* s, rt_scene::FrameSlot& f) {
     fprintf(stderr, "[rt_amd] wave clock shares: raygen %.3f closest %.3f shade %.3f shadow %.3f output %.3f (total %.3g ticks)\n",
             t[0] / sum, t[1] / sum, t[2] / sum, t[3] / sum, t[4] / sum, sum);
     fprintf(stderr, "[rt_amd]   closest: setup %.3f nodes %.3f tris %.3f quads/gates %.3f | shadow: setup %.3f nodes %.3f tris %.3f quads/gates %.3f\n",
-            t[8] / sum, t[9] / sum, t[10] / sum, t[11] / sum, t[12] / sum, t[13] / sum, t[14] / sum, t[15] / sum);
+            t[8] / sum, t[9] / sum, t[10] / sum, t[11] / sum, t[16] / sum, t[17] / sum, t[18] / sum, t[19] / sum);
+    fprintf(stderr, "[rt_amd]   wave-level loop iterations: closest nodes %llu tris %llu quads %llu rounds %llu | shadow nodes %llu tris %llu quads %llu rounds %llu\n",
+            t[12], t[13], t[14], t[15], t[20], t[21], t[22], t[23]);
   }
 #endif
   rt_stats one{};
@@ -3010,6 +3053,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     {
       static unsigned long long before[STAMP_WORDS];
       if (g == 0) memset(before, 0, sizeof before);
+      HIP_TRY(hipStreamSynchronize(s->stream));  // the generation just launched (the copy below does not wait for this stream)
       HIP_TRY(hipMemcpy(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       const unsigned long long* t = s->h_stats + STAT_RAYS + 3 * STAT_SLOTS;
       double d[STAMP_WORDS], sum = 0;
@@ -3019,7 +3063,9 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
       fprintf(stderr, "[rt_amd] generation %d rays %u: ticks per wave %.0f | raygen %.3f closest %.3f shade %.3f shadow %.3f output %.3f\n",
               g, plan.threads[g], sum / waves, d[0] / sum, d[1] / sum, d[2] / sum, d[3] / sum, d[4] / sum);
       fprintf(stderr, "[rt_amd]   closest: setup %.3f nodes %.3f tris %.3f quads/gates %.3f | shadow: setup %.3f nodes %.3f tris %.3f quads/gates %.3f\n",
-              d[8] / sum, d[9] / sum, d[10] / sum, d[11] / sum, d[12] / sum, d[13] / sum, d[14] / sum, d[15] / sum);
+              d[8] / sum, d[9] / sum, d[10] / sum, d[11] / sum, d[16] / sum, d[17] / sum, d[18] / sum, d[19] / sum);
+      fprintf(stderr, "[rt_amd]   wave-level loop iterations: closest nodes %.0f tris %.0f quads %.0f rounds %.0f | shadow nodes %.0f tris %.0f quads %.0f rounds %.0f (waves %.0f)\n",
+              d[12], d[13], d[14], d[15], d[20], d[21], d[22], d[23], waves);
     }
 #endif
   }
@@ -3110,7 +3156,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   in.flags = flags;
   in.camera = true;
   in.cam = camera_dev(camera);
-  in.tiles = s->d_tiles;
+  in.tiles = n_parts == 1 ? nullptr : s->d_tiles;  // the whole image: tile k is tile k, no look-up at the start of every wave
   in.tiles_x = tiles_x;
   if ((flags & RT_FLAG_COMPACT) && (rgb64_dev || hit_leaf_dev || !rgb8_dev))
     return fail(RT_ERR_INVALID, "the compact layout is for rgb8 only");

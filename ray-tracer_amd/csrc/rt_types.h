@@ -164,6 +164,17 @@ struct PatternDev {
   double a[3], b[3];
 };
 
+// A top-level plane kept in the kernel arguments (the floor of nearly every scene): its test needs only
+// the y row of the world -> object matrix (reference src/shape.rs:891-908), so a ray meets it without a
+// memory access.  Planes inside groups, with a transform chain or beyond MAX_INLINE_PLANES stay in
+// `unbounded`.
+constexpr int MAX_INLINE_PLANES = 2;
+struct InlinePlane {
+  double row[4];  // m[4..7]: y of the transformed origin = row . (o, 1), of the direction = row . (d, 0)
+  int32_t leaf;
+  int32_t pad;
+};
+
 struct SceneDev {
   const BvhNode* nodes;
   const TriIsect* tris;
@@ -193,7 +204,8 @@ struct SceneDev {
   int32_t n_bands;
   int32_t band_grid_n;
   int32_t n_csg_unbounded;
-  int32_t pad;
+  int32_t n_inline_planes;
+  InlinePlane inline_planes[MAX_INLINE_PLANES];
   double light_intensity[3];
   double light_position[3];
 };
