@@ -213,6 +213,19 @@ int rt_device_count(void);
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
+/* Shapes moved, the scene stays: `Shape::set_transform` on any shape of the world, which the reference
+ * re-propagates to the children (src/shape.rs:592-656), then the same flattening as for rt_scene_create.
+ * desc must describe the same shape tree (same counts, same leaf types and group / triangle / transform
+ * slots); matrices, group boxes, triangle vertices, materials, patterns and the light are taken from
+ * it.  The acceleration structure keeps its shape and gets new boxes (a refit on the GPU, no rebuild);
+ * a hierarchy refitted many times over large motions traverses slower than a rebuilt one.  From the
+ * first update on every group's bounding-box gate is evaluated exactly as the reference does it (the
+ * shortcut for gates that provably contain their subtree needs a rebuild).  Returns
+ * RT_ERR_UNSUPPORTED when the update needs a rebuild: a shape crossed between bounded and unbounded
+ * (scaled beyond 100, see RT_ERR_UNSUPPORTED above), a transform chain changed its length, or the scene
+ * has CSG operators.  Blocks until frames in flight are done and the update is complete. */
+int rt_scene_update(rt_scene* scene, const rt_scene_desc* desc);
+
 /* A copy of `scene` on `device` (the same GPU or another one of this process): the acceleration structure
  * is not built again, its arrays are copied device to device.  The copy is independent of the original
  * (own streams, own frames in flight) and is released with rt_scene_destroy.  This is how a host that

@@ -113,6 +113,8 @@ def libraries():
     host.rth_scene_camera.argtypes = [vp, C.POINTER(RtCamera)]
     host.rth_scene_set_canvas.argtypes = [vp, u64, u64]
     host.rth_scene_set_camera.argtypes = [vp, u64, u64, C.c_double, dp, dp, dp]
+    host.rth_scene_set_transform.argtypes = [vp, C.POINTER(u64), u64, dp]
+    host.rth_scene_update.argtypes = [vp]
     host.rth_parallel_render.argtypes = [vp, u64, C.c_char_p]
     host.rth_canvas_new.argtypes = [u64, u64, C.POINTER(vp)]
     host.rth_render_canvas.argtypes = [vp, u64, C.POINTER(vp)]
@@ -366,6 +368,21 @@ class Scene:
         u = (C.c_double * 4)(*up[:4])
         self._camera = None
         self._host.rth_scene_set_camera(self._h, width, height, fov, f, t, u)
+
+    def set_transform(self, path, matrix16):
+        """Shape::set_transform (src/shape.rs:592-656) on the shape at `path`: path[0] indexes the world's
+        objects, further entries the children of groups / CSG operators.  Takes effect with update()."""
+        p = (C.c_uint64 * len(path))(*path)
+        m = (C.c_double * 16)(*[float(v) for v in matrix16])
+        rc = self._host.rth_scene_set_transform(self._h, p, len(path), m)
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
+
+    def update(self):
+        """Moves the changed world onto the device: rt_scene_update, a refit of the hierarchy (no rebuild)."""
+        rc = self._host.rth_scene_update(self._h)
+        if rc != 0:
+            raise RtError(rc, self._host.rth_last_error().decode())
 
     def footprint(self):
         b, s = C.c_uint64(), C.c_double()

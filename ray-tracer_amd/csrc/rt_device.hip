@@ -1614,6 +1614,88 @@ __global__ void __launch_bounds__(BLOCK) k_pixel_rays(CameraDev cam, uint32_t n,
 }
 
 // ---------------------------------------------------------------------------
+// refit: new boxes for a hierarchy whose primitives moved (rt_scene_update)
+// ---------------------------------------------------------------------------
+// The reference lets any shape move between renders (Shape::set_transform re-propagates to the
+// children, src/shape.rs:592-656).  The topology of the hierarchy stays; every box is recomputed bottom
+// up from the boxes of the primitive slots.  One thread starts at every node none of whose children is
+// another node (directly or behind a gate); a thread that finishes a node writes the node's box into
+// its slot of the parent and goes on with the parent if it was the last child to arrive.
+struct RefitView {
+  BvhNode* nodes;
+  const float* tri_box;    // 6 floats per TriIsect slot: lo xyz, hi xyz (rounded outward)
+  const float* quad_box;   // the same per QuadPrim slot
+  const Gate* gates;
+  const uint32_t* parent;  // per node: (parent node << 2 | slot), REF_NONE for a node without one
+  const uint32_t* waits;   // per node: children whose box another node delivers
+  uint32_t* arrived;       // per node, zeroed before the launch
+  uint32_t n_nodes;
+};
+
+// A plane another thread (possibly on another compute unit) wrote during this launch: read past the
+// vector L1, which is not coherent between compute units.
+DEV float refit_read(const float* p) {
+  return __uint_as_float(__hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+DEV void refit_run_box(const RefitView& v, uint32_t ref, float lo[3], float hi[3]) {
+  for (int a = 0; a < 3; a++) {
+    lo[a] = INFINITY;
+    hi[a] = -INFINITY;
+  }
+  if (ref == REF_NONE) return;
+  const uint32_t kind = ref >> 30;
+  if (kind != KIND_TRI && kind != KIND_QUAD) return;
+  const float* boxes = kind == KIND_TRI ? v.tri_box : v.quad_box;
+  const uint32_t first = ref & MAX_RUN_FIRST, count = ((ref >> 27) & 7u) + 1u;
+  for (uint32_t i = 0; i < count; i++)
+    for (int a = 0; a < 3; a++) {
+      lo[a] = fminf(lo[a], boxes[(size_t)(first + i) * 6 + a]);
+      hi[a] = fmaxf(hi[a], boxes[(size_t)(first + i) * 6 + 3 + a]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_refit(RefitView v) {
+  uint32_t n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= v.n_nodes || v.waits[n] != 0) return;
+  for (;;) {
+    BvhNode& node = v.nodes[n];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c = 0; c < 4; c++) {
+      uint32_t ref = node.child[c];
+      if (ref != REF_NONE && (ref >> 30) == KIND_GATE) ref = v.gates[ref & 0x3FFFFFFFu].root;  // a run right behind a gate
+      if (ref != REF_NONE && ((ref >> 30) == KIND_TRI || (ref >> 30) == KIND_QUAD)) {
+        float l[3], h[3];
+        refit_run_box(v, ref, l, h);
+        for (int a = 0; a < 3; a++) {
+          node.plane[a][0][c] = l[a];
+          node.plane[a][1][c] = h[a];
+        }
+      }
+      if (node.child[c] != REF_NONE)  // slots of other nodes were written by the threads that finished them
+        for (int a = 0; a < 3; a++) {
+          lo[a] = fminf(lo[a], refit_read(&node.plane[a][0][c]));
+          hi[a] = fmaxf(hi[a], refit_read(&node.plane[a][1][c]));
+        }
+      node.alt[c] = node.child[c];  // after an update every gate is tested (see rt_scene_update)
+    }
+    const uint32_t up = v.parent[n];
+    if (up == REF_NONE) return;
+    BvhNode& p = v.nodes[up >> 2];
+    const uint32_t slot = up & 3u;
+    for (int a = 0; a < 3; a++) {
+      p.plane[a][0][slot] = lo[a];
+      p.plane[a][1][slot] = hi[a];
+    }
+    __threadfence();
+    const uint32_t before = atomicAdd(&v.arrived[up >> 2], 1u);
+    if (before + 1u != v.waits[up >> 2]) return;  // a sibling subtree is still on its way: its thread goes on
+    __threadfence();
+    n = up >> 2;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host side: scene object
 // ---------------------------------------------------------------------------
 namespace {
@@ -1705,6 +1787,24 @@ struct rt_scene {
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
+  // What rt_scene_update needs again: the records in device order, the structure of the description
+  // they were made from, and the device arrays of the refit.
+  struct Host {
+    std::vector<TriIsect> tris;
+    std::vector<QuadPrim> quads, unbounded, band_prims;
+    std::vector<Gate> gates;
+    std::vector<rt_leaf> leaves;            // structure check: type, gate, csg, material / xform / triangle slots
+    std::vector<int32_t> gate_parent;
+    std::vector<rt_chain_ref> xform_chain, gate_chain;
+    std::vector<uint8_t> boxed;             // per leaf: lives in the hierarchy (1) or is tested for every ray (0)
+    std::vector<int32_t> inline_plane_leaf;
+    int32_t n_xforms = 0, n_triangles = 0, n_materials = 0, n_patterns = 0, n_chain_mats = 0, n_csg = 0;
+    uint32_t n_nodes = 0;
+    float *d_tri_box = nullptr, *d_quad_box = nullptr;
+    uint32_t *d_parent = nullptr, *d_waits = nullptr, *d_arrived = nullptr;
+    std::vector<uint32_t> parent, waits;    // host copies (rt_scene_clone uploads them again)
+    bool updated = false;                   // every gate is tested since the first update
+  } host;
 };
 
 namespace {
@@ -1804,6 +1904,106 @@ bool leaf_box(const rt_leaf& L, const rt_xform& X, const rt_triangle* tri, doubl
 }
 
 void copy3x4(double* dst, const double* src16) { memcpy(dst, src16, 12 * sizeof(double)); }
+
+// The tables the shading code reads, from a description.
+struct ShadingTables {
+  std::vector<LeafShade> leaves;
+  std::vector<XformDev> xforms;
+  std::vector<TriShade> tri_shade;
+  std::vector<MaterialDev> mats;
+  std::vector<PatternDev> pats;
+  int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
+  void build(const rt_scene_desc* d) {
+    leaves.resize(d->n_leaves);
+    for (int i = 0; i < d->n_leaves; i++) {
+      const rt_leaf& L = d->leaves[i];
+      LeafShade& o = leaves[i];
+      o.type = L.type; o.closed = L.closed; o.material = L.material; o.xform = L.xform;
+      o.tri = L.tri; o.pad = 0; o.minimum = L.minimum; o.maximum = L.maximum;
+      for (int a = 0; a < 3; a++) o.plane_normal[a] = L.plane_normal[a];
+    }
+    xforms.resize(d->n_xforms);
+    for (int i = 0; i < d->n_xforms; i++) {
+      copy3x4(xforms[i].ray_inv, d->xforms[i].ray_inv);
+      copy3x4(xforms[i].full_inv, d->xforms[i].full_inv);
+    }
+    tri_shade.resize(d->n_triangles);
+    for (int i = 0; i < d->n_triangles; i++) {
+      const rt_triangle& T = d->triangles[i];
+      for (int a = 0; a < 3; a++) {
+        tri_shade[i].normal[a] = T.normal[a];
+        tri_shade[i].n1[a] = T.n1[a];
+        tri_shade[i].n2[a] = T.n2[a];
+        tri_shade[i].n3[a] = T.n3[a];
+      }
+    }
+    mats.resize(d->n_materials);
+    bool any_reflect = false, any_refract = false;
+    for (int i = 0; i < d->n_materials; i++) {
+      const rt_material& M = d->materials[i];
+      MaterialDev& o = mats[i];
+      for (int a = 0; a < 3; a++) o.color[a] = M.color[a];
+      o.ambient = M.ambient; o.diffuse = M.diffuse; o.specular = M.specular; o.shininess = M.shininess;
+      o.reflective = M.reflective; o.refractive_index = M.refractive_index; o.transparency = M.transparency;
+      o.pattern = M.pattern;
+      bool refl = !(fabs(M.reflective - 0.0) < FEQ_EPSILON);      // world.rs:151
+      bool refr = !(fabs(M.transparency - 0.0) < FEQ_EPSILON);    // world.rs:190
+      bool schlick = M.reflective > 0.0 && M.transparency > 0.0;  // world.rs:237
+      o.flags = (refl ? 1 : 0) | (refr ? 2 : 0) | (schlick ? 4 : 0) | ((refr || schlick) ? 8 : 0);
+      any_reflect |= refl;
+      any_refract |= refr;
+    }
+    max_children = (any_reflect ? 1 : 0) + (any_refract ? 1 : 0);
+    pats.resize(d->n_patterns);
+    for (int i = 0; i < d->n_patterns; i++) {
+      const rt_pattern& P = d->patterns[i];
+      pats[i].type = P.type; pats[i].first = P.first; pats[i].second = P.second; pats[i].pad = 0;
+      copy3x4(pats[i].inv, P.inv);
+      for (int a = 0; a < 3; a++) {
+        pats[i].a[a] = P.a[a];
+        pats[i].b[a] = P.b[a];
+      }
+    }
+  }
+};
+
+// The direction pre-filter of a bounded cone's parallel-ray branch (ConeBand) from its world -> object
+// matrix: a(d) = |M d|^2 under diag(1, -1, 1), M = the linear part.
+ConeBand make_cone_band(const QuadPrim& q, uint32_t prim) {
+  const double* m = q.m;
+  const double sg[3] = {1.0, -1.0, 1.0};
+  double Q[3][3], sum = 0.0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      Q[i][j] = 0.0;
+      for (int r = 0; r < 3; r++) Q[i][j] += sg[r] * m[r * 4 + i] * m[r * 4 + j];
+    }
+  ConeBand cb{};
+  cb.q[0] = Q[0][0]; cb.q[1] = Q[1][1]; cb.q[2] = Q[2][2];
+  cb.q[3] = 2.0 * Q[0][1]; cb.q[4] = 2.0 * Q[0][2]; cb.q[5] = 2.0 * Q[1][2];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) sum += m[r * 4 + c] * m[r * 4 + c];
+  cb.slack = 1e-11 * sum;
+  cb.prim = prim;
+  return cb;
+}
+
+// Single-precision copies: the direction's components are rounded to single (2^-24 each, so 2^-23 per
+// product), then six products and five sums within 2^-24 relative each, on top of the rounding of the
+// coefficients: below 1e-6 * sum |q| in all; 4e-6 * sum |q| is added to the slack.
+std::vector<ConeBandF32> cone_bands_f32(const std::vector<ConeBand>& bands) {
+  std::vector<ConeBandF32> out(bands.size());
+  for (size_t i = 0; i < bands.size(); i++) {
+    double sum = 0;
+    for (int c = 0; c < 6; c++) {
+      out[i].q[c] = (float)bands[i].q[c];
+      sum += fabs(bands[i].q[c]);
+    }
+    out[i].slack = std::nextafterf((float)(bands[i].slack + 4e-6 * sum), INFINITY);
+    out[i].prim = bands[i].prim;
+  }
+  return out;
+}
 
 struct SceneBuild {
   const rt_scene_desc* d;
@@ -1961,22 +2161,7 @@ struct SceneBuild {
         it.index = (uint32_t)quad_src.size();
         QuadPrim q = make_quad(li);
         if (L.type == RT_CONE) {
-          // a(d) = |M d|^2 under diag(1, -1, 1), M = the linear part of world -> object
-          const double* m = q.m;
-          const double sg[3] = {1.0, -1.0, 1.0};
-          double Q[3][3], sum = 0.0;
-          for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
-              Q[i][j] = 0.0;
-              for (int r = 0; r < 3; r++) Q[i][j] += sg[r] * m[r * 4 + i] * m[r * 4 + j];
-            }
-          ConeBand cb{};
-          cb.q[0] = Q[0][0]; cb.q[1] = Q[1][1]; cb.q[2] = Q[2][2];
-          cb.q[3] = 2.0 * Q[0][1]; cb.q[4] = 2.0 * Q[0][2]; cb.q[5] = 2.0 * Q[1][2];
-          for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) sum += m[r * 4 + c] * m[r * 4 + c];
-          cb.slack = 1e-11 * sum;
-          cb.prim = (uint32_t)band_prims.size();
+          ConeBand cb = make_cone_band(q, (uint32_t)band_prims.size());
           bands.push_back(cb);
           QuadPrim only = q;
           only.type |= QUAD_ONLY_PARALLEL;
@@ -2072,6 +2257,9 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   if (s->h_stats) (void)hipHostFree(s->h_stats);
   if (s->d_tiles) (void)hipFree(s->d_tiles);
   if (s->stage) (void)hipFree(s->stage);
+  for (void* p : {(void*)s->host.d_tri_box, (void*)s->host.d_quad_box, (void*)s->host.d_parent, (void*)s->host.d_waits,
+                  (void*)s->host.d_arrived})
+    if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev)
     if (e) (void)hipEventDestroy(e);
   for (rt_scene::FrameSlot& f : s->slots) {
@@ -2286,56 +2474,14 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   s->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
   // ---- shading tables
-  std::vector<LeafShade> leaves(d->n_leaves);
-  for (int i = 0; i < d->n_leaves; i++) {
-    const rt_leaf& L = d->leaves[i];
-    LeafShade& o = leaves[i];
-    o.type = L.type; o.closed = L.closed; o.material = L.material; o.xform = L.xform;
-    o.tri = L.tri; o.pad = 0; o.minimum = L.minimum; o.maximum = L.maximum;
-    for (int a = 0; a < 3; a++) o.plane_normal[a] = L.plane_normal[a];
-  }
-  std::vector<XformDev> xforms(d->n_xforms);
-  for (int i = 0; i < d->n_xforms; i++) {
-    copy3x4(xforms[i].ray_inv, d->xforms[i].ray_inv);
-    copy3x4(xforms[i].full_inv, d->xforms[i].full_inv);
-  }
-  std::vector<TriShade> tri_shade(d->n_triangles);
-  for (int i = 0; i < d->n_triangles; i++) {
-    const rt_triangle& T = d->triangles[i];
-    for (int a = 0; a < 3; a++) {
-      tri_shade[i].normal[a] = T.normal[a];
-      tri_shade[i].n1[a] = T.n1[a];
-      tri_shade[i].n2[a] = T.n2[a];
-      tri_shade[i].n3[a] = T.n3[a];
-    }
-  }
-  std::vector<MaterialDev> mats(d->n_materials);
-  bool any_reflect = false, any_refract = false;
-  for (int i = 0; i < d->n_materials; i++) {
-    const rt_material& M = d->materials[i];
-    MaterialDev& o = mats[i];
-    for (int a = 0; a < 3; a++) o.color[a] = M.color[a];
-    o.ambient = M.ambient; o.diffuse = M.diffuse; o.specular = M.specular; o.shininess = M.shininess;
-    o.reflective = M.reflective; o.refractive_index = M.refractive_index; o.transparency = M.transparency;
-    o.pattern = M.pattern;
-    bool refl = !(fabs(M.reflective - 0.0) < FEQ_EPSILON);      // world.rs:151
-    bool refr = !(fabs(M.transparency - 0.0) < FEQ_EPSILON);    // world.rs:190
-    bool schlick = M.reflective > 0.0 && M.transparency > 0.0;  // world.rs:237
-    o.flags = (refl ? 1 : 0) | (refr ? 2 : 0) | (schlick ? 4 : 0) | ((refr || schlick) ? 8 : 0);
-    any_reflect |= refl;
-    any_refract |= refr;
-  }
-  s->max_children = (any_reflect ? 1 : 0) + (any_refract ? 1 : 0);
-  std::vector<PatternDev> pats(d->n_patterns);
-  for (int i = 0; i < d->n_patterns; i++) {
-    const rt_pattern& P = d->patterns[i];
-    pats[i].type = P.type; pats[i].first = P.first; pats[i].second = P.second; pats[i].pad = 0;
-    copy3x4(pats[i].inv, P.inv);
-    for (int a = 0; a < 3; a++) {
-      pats[i].a[a] = P.a[a];
-      pats[i].b[a] = P.b[a];
-    }
-  }
+  ShadingTables sh;
+  sh.build(d);
+  s->max_children = sh.max_children;
+  std::vector<LeafShade>& leaves = sh.leaves;
+  std::vector<XformDev>& xforms = sh.xforms;
+  std::vector<TriShade>& tri_shade = sh.tri_shade;
+  std::vector<MaterialDev>& mats = sh.mats;
+  std::vector<PatternDev>& pats = sh.pats;
 
   // ---- upload
   int rc;
@@ -2366,19 +2512,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   s->dev.n_csg_unbounded = (int32_t)b.csg_unbounded.size();
   if ((rc = upload(s, b.bands, &s->dev.bands))) return rc;
   {
-    // single-precision copies: the direction's components are rounded to single (2^-24 each, so
-    // 2^-23 per product), then six products and five sums within 2^-24 relative each, on top of the
-    // rounding of the coefficients: below 1e-6 * sum |q| in all; 4e-6 * sum |q| is added to the slack
-    std::vector<ConeBandF32> bands32(b.bands.size());
-    for (size_t i = 0; i < b.bands.size(); i++) {
-      double sum = 0;
-      for (int c = 0; c < 6; c++) {
-        bands32[i].q[c] = (float)b.bands[i].q[c];
-        sum += fabs(b.bands[i].q[c]);
-      }
-      bands32[i].slack = std::nextafterf((float)(b.bands[i].slack + 4e-6 * sum), INFINITY);
-      bands32[i].prim = b.bands[i].prim;
-    }
+    std::vector<ConeBandF32> bands32 = cone_bands_f32(b.bands);
     if ((rc = upload(s, bands32, &s->dev.bands32))) return rc;
   }
   if ((rc = upload(s, b.band_prims, &s->dev.band_prims))) return rc;
@@ -2433,6 +2567,42 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if ((rc = upload(s, pats, &s->dev.patterns))) return rc;
   s->dev.root = root;
   s->dev.root_alt = b.bvh.alt(root);
+  {  // the host copy rt_scene_update works from
+    rt_scene::Host& H = s->host;
+    H.tris = tris;
+    H.quads = quads;
+    H.unbounded = b.unbounded;
+    H.band_prims = b.band_prims;
+    H.gates = b.gates;
+    H.leaves.assign(d->leaves, d->leaves + d->n_leaves);
+    H.gate_parent.resize(d->n_gates);
+    for (int i = 0; i < d->n_gates; i++) H.gate_parent[i] = d->gates[i].parent;
+    if (d->xform_chain) H.xform_chain.assign(d->xform_chain, d->xform_chain + d->n_xforms);
+    if (d->gate_chain) H.gate_chain.assign(d->gate_chain, d->gate_chain + d->n_gates);
+    H.boxed.assign((size_t)d->n_leaves, 0);
+    for (size_t i = 0; i < b.bvh.tri_order.size(); i++) H.boxed[(size_t)tris[i].leaf] = 1;
+    for (size_t i = 0; i < b.bvh.quad_order.size(); i++) H.boxed[(size_t)quads[i].leaf] = 1;
+    for (int i = 0; i < s->dev.n_inline_planes; i++) H.inline_plane_leaf.push_back(s->dev.inline_planes[i].leaf);
+    H.n_xforms = d->n_xforms; H.n_triangles = d->n_triangles; H.n_materials = d->n_materials;
+    H.n_patterns = d->n_patterns; H.n_chain_mats = d->n_chain_mats; H.n_csg = d->n_csg;
+    // who delivers the box of every node: its parent slot, through a gate when the node is a group's root
+    const std::vector<BvhNode>& nodes = b.bvh.nodes;
+    H.n_nodes = (uint32_t)nodes.size();
+    H.parent.assign(nodes.size(), REF_NONE);
+    H.waits.assign(nodes.size(), 0u);
+    for (size_t n = 0; n < nodes.size(); n++)
+      for (int c = 0; c < 4; c++) {
+        uint32_t ref = nodes[n].child[c];
+        if (ref != REF_NONE && (ref >> 30) == KIND_GATE) {
+          const Gate& g = b.gates[ref & 0x3FFFFFFFu];
+          ref = g.csg ? REF_NONE : g.root;
+        }
+        if (ref != REF_NONE && (ref >> 30) == KIND_INNER) {
+          H.parent[ref & 0x3FFFFFFFu] = (uint32_t)(n << 2) | (uint32_t)c;
+          H.waits[n]++;
+        }
+      }
+  }
   // Measured: the scalar path for wave-uniform nodes pays off for hierarchies far beyond the 32 KB L1
   // of a CU (1M-triangle mesh: -6 % frame time) and costs a few percent on small ones (12k triangles:
   // +5 %), whose upper levels stay in L1 anyway.
@@ -2473,6 +2643,241 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   return RT_OK;
 }
 
+namespace {
+int collect_all(rt_scene* s);  // waits for the frames in flight (defined with the pipeline below)
+}
+
+// Finds the device array a pointer of `dev` owns.
+static const rt_scene::Alloc* alloc_of(const rt_scene* s, size_t field) {
+  for (const rt_scene::Alloc& a : s->allocs)
+    if (a.field == field) return &a;
+  return nullptr;
+}
+template <class T>
+static int reupload(rt_scene* s, size_t field, const std::vector<T>& v) {
+  if (v.empty()) return RT_OK;
+  const rt_scene::Alloc* a = alloc_of(s, field);
+  if (!a || a->bytes != v.size() * sizeof(T)) return fail(RT_ERR_INVALID, "rt_scene_update: a table changed size");
+  HIP_TRY(hipMemcpy(a->p, v.data(), a->bytes, hipMemcpyHostToDevice));
+  return RT_OK;
+}
+#define RT_FIELD(f) offsetof(SceneDev, f)
+
+static void box_to_f32(const double lo[3], const double hi[3], float* out6) {
+  for (int a = 0; a < 3; a++) {
+    float l = (float)lo[a], h = (float)hi[a];
+    out6[a] = (double)l > lo[a] ? std::nextafterf(l, -INFINITY) : l;
+    out6[3 + a] = (double)h < hi[a] ? std::nextafterf(h, INFINITY) : h;
+  }
+}
+
+static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
+  rt_scene::Host& H = s->host;
+  // ---- the shape tree must be the one the scene was built from
+  if (d->n_leaves != (int32_t)H.leaves.size() || d->n_gates != (int32_t)H.gate_parent.size() || d->n_xforms != H.n_xforms ||
+      d->n_triangles != H.n_triangles || d->n_materials != H.n_materials || d->n_patterns != H.n_patterns ||
+      d->n_chain_mats != H.n_chain_mats || d->n_csg != H.n_csg)
+    return fail(RT_ERR_INVALID, "rt_scene_update: the description has other counts than the scene was built from");
+  if (H.n_csg > 0) return fail(RT_ERR_UNSUPPORTED, "rt_scene_update: scenes with CSG operators are rebuilt, not updated");
+  if ((d->n_leaves > 0 && !d->leaves) || (d->n_gates > 0 && !d->gates) || (d->n_xforms > 0 && !d->xforms) ||
+      (d->n_triangles > 0 && !d->triangles) || (d->n_materials > 0 && !d->materials) || (d->n_patterns > 0 && !d->patterns) ||
+      (d->n_chain_mats > 0 && !d->chain_mats))
+    return fail(RT_ERR_INVALID, "null array with a positive count in scene description");
+  for (int i = 0; i < d->n_leaves; i++) {
+    const rt_leaf &A = d->leaves[i], &B = H.leaves[(size_t)i];
+    if (A.type != B.type || A.gate != B.gate || A.csg != B.csg || A.xform != B.xform || A.tri != B.tri || A.closed != B.closed)
+      return fail(RT_ERR_INVALID, "rt_scene_update: the shape tree differs from the one the scene was built from");
+    if (A.material < 0 || A.material >= d->n_materials) return fail(RT_ERR_INVALID, "leaf material out of range");
+  }
+  for (int i = 0; i < d->n_gates; i++) {
+    if (d->gates[i].parent != H.gate_parent[(size_t)i])
+      return fail(RT_ERR_INVALID, "rt_scene_update: the group tree differs from the one the scene was built from");
+    if (!affine(d->gates[i].to_local)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) group transform");
+  }
+  for (int i = 0; i < d->n_xforms; i++)
+    if (!affine(d->xforms[i].ray_inv) || !affine(d->xforms[i].full_inv) || !affine(d->xforms[i].fwd))
+      return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) shape transform: last row must be 0 0 0 1");
+  for (int i = 0; i < d->n_chain_mats; i++)
+    if (!affine(d->chain_mats + 16 * (size_t)i)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) matrix in a transform chain");
+  for (int pass = 0; pass < 2; pass++) {  // the chains keep their places (their matrices may change)
+    const rt_chain_ref* now = pass ? d->gate_chain : d->xform_chain;
+    const std::vector<rt_chain_ref>& then = pass ? H.gate_chain : H.xform_chain;
+    const int n = pass ? d->n_gates : d->n_xforms;
+    for (int i = 0; i < n; i++) {
+      const rt_chain_ref a = now ? now[i] : rt_chain_ref{0, 0}, b = then.empty() ? rt_chain_ref{0, 0} : then[(size_t)i];
+      if (a.count != b.count || (a.count > 0 && a.first != b.first))
+        return fail(RT_ERR_UNSUPPORTED, "rt_scene_update: a transform chain changed its length (an identity level became a transform or the reverse): rebuild the scene");
+    }
+  }
+  for (int i = 0; i < d->n_patterns; i++) {
+    const rt_pattern& P = d->patterns[i];
+    if (!affine(P.inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) pattern transform");
+    if (P.type < RT_PAT_NULL || P.type > RT_PAT_BLEND) return fail(RT_ERR_INVALID, "unknown pattern type");
+    if (P.type == RT_PAT_BLEND && (P.first < 0 || P.first >= d->n_patterns || P.second < 0 || P.second >= d->n_patterns))
+      return fail(RT_ERR_INVALID, "blend pattern operand out of range");
+  }
+  for (int i = 0; i < d->n_materials; i++)
+    if (d->materials[i].pattern < -1 || d->materials[i].pattern >= d->n_patterns)
+      return fail(RT_ERR_INVALID, "material pattern index out of range");
+
+  SceneBuild b;
+  b.d = d;
+  // ---- every shape stays where it is: in the hierarchy, or among the shapes tested for every ray
+  std::vector<float> tri_box(H.tris.size() * 6, 0.0f), quad_box(H.quads.size() * 6, 0.0f);
+  std::vector<TriIsect> tris(H.tris.size());
+  std::vector<QuadPrim> quads(H.quads.size()), unbounded(H.unbounded.size()), band_prims(H.band_prims.size());
+  std::vector<ConeBand> bands(H.band_prims.size());
+  auto box_of_leaf = [&](int li, double lo[3], double hi[3]) {
+    const rt_leaf& L = d->leaves[li];
+    const bool tri = L.type == RT_TRIANGLE || L.type == RT_SMOOTH_TRIANGLE;
+    return leaf_box(L, d->xforms[L.xform], tri ? &d->triangles[L.tri] : nullptr, lo, hi);
+  };
+  for (int li = 0; li < d->n_leaves; li++) {
+    if (d->leaves[li].type == RT_EMPTY) continue;
+    double lo[3], hi[3];
+    if (box_of_leaf(li, lo, hi) != (H.boxed[(size_t)li] != 0))
+      return fail(RT_ERR_UNSUPPORTED, "rt_scene_update: a shape crossed between the hierarchy and the shapes tested for every ray "
+                                      "(it became unbounded, or bounded): rebuild the scene");
+  }
+  for (size_t i = 0; i < tris.size(); i++) {
+    const int li = H.tris[i].leaf;
+    tris[i] = b.make_tri(li);
+    double lo[3], hi[3];
+    box_of_leaf(li, lo, hi);
+    box_to_f32(lo, hi, &tri_box[i * 6]);
+  }
+  for (size_t i = 0; i < quads.size(); i++) {
+    const int li = H.quads[i].leaf;
+    quads[i] = b.make_quad(li);
+    quads[i].type |= H.quads[i].type & QUAD_SKIP_PARALLEL;
+    double lo[3], hi[3];
+    box_of_leaf(li, lo, hi);
+    box_to_f32(lo, hi, &quad_box[i * 6]);
+  }
+  for (size_t i = 0; i < unbounded.size(); i++) unbounded[i] = b.make_quad(H.unbounded[i].leaf);
+  for (size_t i = 0; i < band_prims.size(); i++) {
+    band_prims[i] = b.make_quad(H.band_prims[i].leaf);
+    bands[i] = make_cone_band(band_prims[i], (uint32_t)i);
+    band_prims[i].type |= QUAD_ONLY_PARALLEL;
+  }
+  std::vector<Gate> gates = H.gates;
+  for (int gi = 0; gi < d->n_gates; gi++) {
+    Gate& g = gates[(size_t)gi];
+    const rt_gate& G = d->gates[gi];
+    copy3x4(g.m, G.to_local);
+    b.gate_chain(gi, g);
+    for (int a = 0; a < 3; a++) {
+      g.bmin[a] = G.bmin[a];
+      g.bmax[a] = G.bmax[a];
+    }
+    // Whether the exact test of a group may be skipped depends on its box containing everything below,
+    // which only the refit knows: from the first update on every gate is tested.
+    g.skippable = 0;
+  }
+  ShadingTables sh;
+  sh.build(d);
+
+  // ---- nothing may be in flight while the tables change
+  int rc = collect_all(s);
+  if (rc) return rc;
+  for (hipStream_t st : {s->stream, s->frame_stream, s->copy_stream}) HIP_TRY(hipStreamSynchronize(st));
+  if ((rc = reupload(s, RT_FIELD(tris), tris))) return rc;
+  if ((rc = reupload(s, RT_FIELD(quads), quads))) return rc;
+  if ((rc = reupload(s, RT_FIELD(gates), gates))) return rc;
+  if ((rc = reupload(s, RT_FIELD(unbounded), unbounded))) return rc;
+  if ((rc = reupload(s, RT_FIELD(band_prims), band_prims))) return rc;
+  if ((rc = reupload(s, RT_FIELD(bands), bands))) return rc;
+  if ((rc = reupload(s, RT_FIELD(bands32), cone_bands_f32(bands)))) return rc;
+  if ((rc = reupload(s, RT_FIELD(leaves), sh.leaves))) return rc;
+  if ((rc = reupload(s, RT_FIELD(xforms), sh.xforms))) return rc;
+  if ((rc = reupload(s, RT_FIELD(tri_shade), sh.tri_shade))) return rc;
+  if ((rc = reupload(s, RT_FIELD(materials), sh.mats))) return rc;
+  if ((rc = reupload(s, RT_FIELD(patterns), sh.pats))) return rc;
+  if (s->dev.chain_mats) {
+    std::vector<double> chain_mats((size_t)d->n_chain_mats * 12);
+    for (int i = 0; i < d->n_chain_mats; i++) copy3x4(&chain_mats[(size_t)i * 12], d->chain_mats + 16 * (size_t)i);
+    if ((rc = reupload(s, RT_FIELD(chain_mats), chain_mats))) return rc;
+  }
+  for (int i = 0; i < s->dev.n_inline_planes; i++) {
+    const QuadPrim q = b.make_quad(H.inline_plane_leaf[(size_t)i]);
+    for (int k = 0; k < 4; k++) s->dev.inline_planes[i].row[k] = q.m[4 + k];
+  }
+  for (int a = 0; a < 3; a++) {
+    s->dev.light_intensity[a] = d->light.intensity[a];
+    s->dev.light_position[a] = d->light.position[a];
+  }
+  s->max_children = sh.max_children;
+  s->hint_valid = false;
+  // ---- the cones' direction index follows their new matrices
+  if (s->dev.band_grid_n > 0) {
+    for (size_t field : {RT_FIELD(band_start), RT_FIELD(band_items)})
+      for (size_t k = 0; k < s->allocs.size(); k++)
+        if (s->allocs[k].field == field) {
+          s->scene_bytes -= s->allocs[k].bytes;
+          (void)hipFree(s->allocs[k].p);
+          s->allocs.erase(s->allocs.begin() + (long)k);
+          break;
+        }
+    s->dev.band_start = s->dev.band_items = nullptr;
+    s->dev.band_grid_n = 0;
+    int n = 0;
+    uint32_t *d_start = nullptr, *d_items = nullptr;
+    size_t n_items = 0;
+    if ((rc = build_band_grid_device(s->dev.bands, bands.size(), (size_t)1 << 30, &n, &d_start, &d_items, &n_items))) return rc;
+    s->dev.band_grid_n = n;
+    s->dev.band_start = d_start;
+    s->dev.band_items = d_items;
+    if (d_start) {
+      s->allocs.push_back(rt_scene::Alloc{d_start, ((size_t)3 * n * n + 1) * 4, RT_FIELD(band_start)});
+      s->scene_bytes += ((size_t)3 * n * n + 1) * 4;
+    }
+    if (d_items) {
+      s->allocs.push_back(rt_scene::Alloc{d_items, (n_items + 1) * 4, RT_FIELD(band_items)});
+      s->scene_bytes += (n_items + 1) * 4;
+    }
+  }
+  // ---- the hierarchy keeps its shape and gets new boxes
+  if (H.n_nodes > 0) {
+    if (!H.d_parent) {
+      HIP_TRY(hipMalloc((void**)&H.d_parent, H.n_nodes * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc((void**)&H.d_waits, H.n_nodes * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc((void**)&H.d_arrived, H.n_nodes * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc((void**)&H.d_tri_box, std::max<size_t>(1, tri_box.size()) * sizeof(float)));
+      HIP_TRY(hipMalloc((void**)&H.d_quad_box, std::max<size_t>(1, quad_box.size()) * sizeof(float)));
+      HIP_TRY(hipMemcpy(H.d_parent, H.parent.data(), H.n_nodes * sizeof(uint32_t), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(H.d_waits, H.waits.data(), H.n_nodes * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (!tri_box.empty()) HIP_TRY(hipMemcpy(H.d_tri_box, tri_box.data(), tri_box.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!quad_box.empty()) HIP_TRY(hipMemcpy(H.d_quad_box, quad_box.data(), quad_box.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(H.d_arrived, 0, H.n_nodes * sizeof(uint32_t), s->stream));
+    RefitView v{const_cast<BvhNode*>(s->dev.nodes), H.d_tri_box, H.d_quad_box, s->dev.gates, H.d_parent, H.d_waits, H.d_arrived, H.n_nodes};
+    hipLaunchKernelGGL(k_refit, dim3((H.n_nodes + 255) / 256), dim3(256), 0, s->stream, v);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  s->dev.root_alt = s->dev.root;  // with every gate tested, both kinds of ray walk the same references
+  H.tris.swap(tris);
+  H.quads.swap(quads);
+  H.unbounded.swap(unbounded);
+  H.band_prims.swap(band_prims);
+  H.gates.swap(gates);
+  H.updated = true;
+  return RT_OK;
+}
+#undef RT_FIELD
+
+extern "C" int rt_scene_update(rt_scene* s, const rt_scene_desc* desc) {
+  if (!s || !desc) return fail(RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  try {
+    return scene_update_impl(s, desc);
+  } catch (const std::bad_alloc&) {
+    return fail(RT_ERR_NOMEM, "out of host memory while updating the scene");
+  } catch (const std::exception& e) {
+    return fail(RT_ERR_INVALID, e.what());
+  }
+}
+
 // A second copy of a scene on another GPU (or the same one): the acceleration structure is built once
 // and its arrays are copied device to device.
 extern "C" int rt_scene_clone(const rt_scene* src, int device, rt_scene** out) {
@@ -2499,6 +2904,9 @@ extern "C" int rt_scene_clone(const rt_scene* src, int device, rt_scene** out) {
     s->has_csg = src->has_csg;
     s->uniform_nodes = src->uniform_nodes;
     s->max_children = src->max_children;
+    s->host = src->host;  // vectors copied; the refit's device arrays are made on the first update
+    s->host.d_tri_box = s->host.d_quad_box = nullptr;
+    s->host.d_parent = s->host.d_waits = s->host.d_arrived = nullptr;
     return RT_OK;
   };
   int rc = work();

@@ -100,6 +100,36 @@ void rth_scene_set_camera(rth_scene* h, uint64_t w, uint64_t hh, double fov, con
   h->scene.camera = Camera::make(w, hh, fov, view_transform(from, to, up4));
 }
 
+// Shape::set_transform (src/shape.rs:592-656) on the shape reached from world.objects by `path`
+// (path[0] indexes the objects, every further entry the children of a group or CSG operator).
+int rth_scene_set_transform(rth_scene* h, const uint64_t* path, uint64_t depth, const double* m16) {
+  return guarded([&]() -> int {
+    if (depth == 0) throw Panic("empty shape path");
+    std::vector<Shape>* level = &h->scene.world.objects;
+    Shape* shape = nullptr;
+    for (uint64_t k = 0; k < depth; k++) {
+      if (path[k] >= level->size()) throw Panic("shape path leaves the tree");
+      shape = &(*level)[path[k]];
+      level = &shape->children;
+    }
+    memcpy(shape->transform.m, m16, sizeof(shape->transform.m));
+    return RT_OK;
+  });
+}
+
+// The world as it is now, on the device: flattened again, then rt_scene_update (new boxes for the same
+// hierarchy, no rebuild).  RT_ERR_UNSUPPORTED when the change needs a rebuild.
+int rth_scene_update(rth_scene* h) {
+  return guarded([&]() -> int {
+    if (!h->dev) throw Panic("scene was loaded without a device");
+    h->flat = flatten(h->scene.world);
+    rt_scene_desc d = h->flat.desc();
+    int rc = rt_scene_update(h->dev, &d);
+    if (rc != RT_OK) g_err = rt_last_error();
+    return rc;
+  });
+}
+
 // parallel_render: jobs GPUs, writes the PPM.
 int rth_parallel_render(rth_scene* h, uint64_t jobs, const char* out_path) {
   return guarded([&]() -> int {
