@@ -213,6 +213,19 @@ int rt_device_count(void);
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
+/* The same with a choice of builder for the acceleration structure.  RT_BUILD_DEVICE: subtrees of 2048
+ * items or more are built on the GPU (Morton order, binary radix tree, collapsed to the 4-wide layout:
+ * milliseconds for a million triangles, for scenes that are built often); without it the host builds
+ * them with a binned surface-area heuristic (slower to build, faster to traverse: the default).  Both
+ * are conservative hierarchies over the same shapes, so the images are the same; the reference has
+ * neither (it scans every child of a group, src/shape.rs:1213-1219).  RT_AMD_DEVICE_BVH=1 / 0 in the
+ * environment overrides the flag, RT_AMD_DEVICE_BVH_MIN the 2048. */
+enum { RT_BUILD_DEVICE = 1 };
+int rt_scene_create_with(const rt_scene_desc* desc, int device, uint32_t build_flags, rt_scene** out);
+/* How many subtrees the GPU builder made for this scene and the seconds it took (of the build_seconds
+ * rt_scene_footprint reports). */
+int rt_scene_build_info(const rt_scene* scene, uint64_t* device_builds, double* device_build_seconds);
+
 /* Shapes moved, the scene stays: `Shape::set_transform` on any shape of the world, which the reference
  * re-propagates to the children (src/shape.rs:592-656), then the same flattening as for rt_scene_create.
  * desc must describe the same shape tree (same counts, same leaf types and group / triangle / transform

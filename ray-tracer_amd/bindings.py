@@ -87,6 +87,7 @@ def libraries():
     amd.rt_last_error.restype = C.c_char_p
     amd.rt_device_count.restype = i32
     amd.rt_scene_footprint.argtypes = [vp, C.POINTER(u64), dp]
+    amd.rt_scene_build_info.argtypes = [vp, C.POINTER(u64), dp]
     amd.rt_render.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
     amd.rt_scene_wait.argtypes = [vp, C.POINTER(RtStats)]
     amd.rt_scene_stream.argtypes = [vp, C.POINTER(vp)]
@@ -387,7 +388,9 @@ class Scene:
     def footprint(self):
         b, s = C.c_uint64(), C.c_double()
         self._check(self._amd.rt_scene_footprint(self._dev(), C.byref(b), C.byref(s)))
-        return {"scene_bytes": b.value, "build_seconds": s.value}
+        n, t = C.c_uint64(), C.c_double()
+        self._check(self._amd.rt_scene_build_info(self._dev(), C.byref(n), C.byref(t)))
+        return {"scene_bytes": b.value, "build_seconds": s.value, "device_builds": n.value, "device_build_seconds": t.value}
 
     def _dev(self):
         d = self._host.rth_scene_device(self._h)

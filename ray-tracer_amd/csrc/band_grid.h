@@ -31,4 +31,8 @@ int band_grid_first_n(size_t n_bands);
 int build_band_grid_device(const ConeBand* d_bands, size_t n_bands, size_t max_items, int* n_out, uint32_t** d_start,
                            uint32_t** d_items, size_t* n_items);
 
+// The entries of a grid on the device as 16-bit numbers (for fewer than 65536 bands): *out is a new
+// hipMalloc'ed array of n_items entries, d_items is freed.  Returns 0 or a negative rt_status.
+int compress_band_items_u16(uint32_t* d_items, size_t n_items, uint16_t** out);
+
 }  // namespace rt

@@ -236,6 +236,32 @@ done:
   return rc;
 }
 
+// The entries of a finished index as 16-bit numbers (for fewer than 65536 cones): half the memory, and
+// half the bytes a ray reads per entry.  Frees the 32-bit array.
+namespace {
+__global__ void __launch_bounds__(THREADS) k_items_to_u16(const uint32_t* in, size_t n, uint16_t* out) {
+  const size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x;
+  if (i < n) out[i] = (uint16_t)in[i];
+}
+}  // namespace
+
+int compress_band_items_u16(uint32_t* d_items, size_t n_items, uint16_t** out) {
+  *out = nullptr;
+  uint16_t* p = nullptr;
+  hipError_t e = hipMalloc((void**)&p, (n_items + 2) * sizeof(uint16_t));
+  if (e != hipSuccess) return rt_fail_message(RT_ERR_NOMEM, "no device memory for the cone direction index");
+  if (n_items) hipLaunchKernelGGL(k_items_to_u16, dim3((unsigned)((n_items + THREADS - 1) / THREADS)), dim3(THREADS), 0, 0, (const uint32_t*)d_items, n_items, p);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return rt_fail_message(RT_ERR_DEVICE, (std::string("k_items_to_u16: ") + hipGetErrorString(e)).c_str());
+  }
+  (void)hipFree(d_items);
+  *out = p;
+  return RT_OK;
+}
+
 }  // namespace rt
 
 // Diagnostic: builds the index over n_bands random cones on the host and on `device` and compares

@@ -318,6 +318,48 @@ uint32_t BvhBuilder::build(std::vector<BuildItem>& items, double lo[3], double h
     stack_need = 0;
     return REF_NONE;
   }
+  if (on_device && items.size() >= device_min_items && items.size() >= 2) {
+    DeviceBvh d;
+    if (build_bvh_device(items.data(), items.size(), gate_alt, gate_need, &d) == 0) {
+      const uint32_t node_off = (uint32_t)nodes.size(), tri_off = (uint32_t)tri_order.size(), quad_off = (uint32_t)quad_order.size();
+      auto moved = [&](uint32_t r) -> uint32_t {
+        if (r == REF_NONE) return r;
+        switch (r >> 30) {
+          case KIND_INNER: return r + node_off;
+          case KIND_TRI: return r + tri_off;
+          case KIND_QUAD: return r + quad_off;
+          default: return r;
+        }
+      };
+      for (BvhNode nd : d.nodes) {
+        for (int c = 0; c < 4; c++) {
+          const bool gate = nd.child[c] != REF_NONE && (nd.child[c] >> 30) == KIND_GATE;
+          nd.child[c] = moved(nd.child[c]);
+          if (!gate) nd.alt[c] = nd.child[c];  // a gate's alternative is a reference of this builder already
+        }
+        nodes.push_back(nd);
+      }
+      tri_order.insert(tri_order.end(), d.tri_order.begin(), d.tri_order.end());
+      quad_order.insert(quad_order.end(), d.quad_order.begin(), d.quad_order.end());
+      for (int a = 0; a < 3; a++) {
+        lo[a] = INF;
+        hi[a] = -INF;
+      }
+      for (const BuildItem& it : items)
+        for (int a = 0; a < 3; a++) {
+          lo[a] = std::min(lo[a], it.lo[a]);
+          hi[a] = std::max(hi[a], it.hi[a]);
+        }
+      stack_need = d.stack_need;
+      device_seconds += d.seconds;
+      device_builds++;
+      if (getenv("RT_AMD_BUILD_TIMING"))
+        fprintf(stderr, "[rt_amd] device build of %zu items: %.2f ms, %zu nodes in %d levels, stack need %d\n", items.size(),
+                d.seconds * 1e3, d.nodes.size(), d.levels, d.stack_need);
+      return moved(d.root);
+    }
+    // refused (too deep, too large): the host builder takes over
+  }
   bin_.clear();
   static const int default_threads = [] {
     int t = env_int("RT_AMD_BUILD_THREADS", 0);

@@ -768,11 +768,15 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
           }
         }
       };
+      const uint16_t* items16 = reinterpret_cast<const uint16_t*>(S.band_items);
       for (uint32_t k = S.band_start[cell]; k < end; k += RT_BAND_BATCH) {
         uint32_t id[RT_BAND_BATCH];
         ConeBandF32 f[RT_BAND_BATCH];
 #pragma unroll
-        for (int j = 0; j < RT_BAND_BATCH; j++) id[j] = S.band_items[min(k + j, end - 1)];
+        for (int j = 0; j < RT_BAND_BATCH; j++) {
+          const uint32_t at = min(k + j, end - 1);
+          id[j] = S.band_items16 ? (uint32_t)items16[at] : S.band_items[at];
+        }
 #pragma unroll
         for (int j = 0; j < RT_BAND_BATCH; j++) f[j] = S.bands32[id[j]];
         if (__any(st.sp + RT_BAND_BATCH > Stack::ENTRIES)) drain();
@@ -1751,6 +1755,8 @@ struct rt_scene {
   std::vector<Alloc> allocs;
   uint64_t scene_bytes = 0;
   double build_seconds = 0;
+  double device_build_seconds = 0;  // of build_seconds: inside the GPU builder (upload, kernels, download)
+  size_t device_builds = 0;         // subtrees the GPU builder made
   int stack_need = 1;
   bool has_csg = false;
   // queue lengths per generation of the last multi-generation frame: the next frame is launched on them
@@ -2310,7 +2316,9 @@ static int scene_runtime_init(rt_scene* s, int device) {
   return RT_OK;
 }
 
-static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
+static int attach_band_grid(rt_scene* s, size_t n_bands);
+
+static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_flags, rt_scene* s) {
   // ---- validate
   if (d->n_leaves < 0 || d->n_gates < 0 || d->n_xforms < 0 || d->n_triangles < 0 || d->n_materials < 0 ||
       d->n_patterns < 0)
@@ -2405,6 +2413,12 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   auto t0 = std::chrono::steady_clock::now();
   SceneBuild b;
   b.d = d;
+  {  // where the hierarchy is built: RT_BUILD_DEVICE, or RT_AMD_DEVICE_BVH=1 / 0 in the environment
+    bool on_device = (build_flags & RT_BUILD_DEVICE) != 0;
+    if (const char* e = getenv("RT_AMD_DEVICE_BVH")) on_device = atoi(e) != 0;
+    b.bvh.on_device = on_device;
+    if (const char* e = getenv("RT_AMD_DEVICE_BVH_MIN")) b.bvh.device_min_items = (size_t)std::max(2, atoi(e));
+  }
   b.gate_children.resize(d->n_gates);
   b.gate_leaves.resize(d->n_gates);
   b.gates.reserve((size_t)d->n_gates + (size_t)d->n_csg);
@@ -2472,6 +2486,8 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
   if (tris.size() > MAX_RUN_FIRST || quads.size() > MAX_RUN_FIRST) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
   s->has_csg = !b.csg_roots.empty() || any_chain;  // either needs the general kernels
   s->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  s->device_build_seconds = b.bvh.device_seconds;
+  s->device_builds = b.bvh.device_builds;
 
   // ---- shading tables
   ShadingTables sh;
@@ -2529,25 +2545,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
       fprintf(stderr, "[rt_amd] band grid n=%d cells=%zu entries=%zu\n", grid.n, grid.start.size(), grid.items.size());
   } else {
     // built on this GPU from the bands just uploaded: milliseconds where the host builder takes seconds
-    const auto g0 = std::chrono::steady_clock::now();
-    int n = 0;
-    uint32_t *d_start = nullptr, *d_items = nullptr;
-    size_t n_items = 0;
-    if ((rc = build_band_grid_device(s->dev.bands, b.bands.size(), (size_t)1 << 30, &n, &d_start, &d_items, &n_items))) return rc;
-    s->dev.band_grid_n = n;
-    s->dev.band_start = d_start;
-    s->dev.band_items = d_items;
-    if (d_start) {
-      s->allocs.push_back(rt_scene::Alloc{d_start, ((size_t)3 * n * n + 1) * 4, offsetof(SceneDev, band_start)});
-      s->scene_bytes += ((size_t)3 * n * n + 1) * 4;
-    }
-    if (d_items) {
-      s->allocs.push_back(rt_scene::Alloc{d_items, (n_items + 1) * 4, offsetof(SceneDev, band_items)});
-      s->scene_bytes += n_items * 4;
-    }
-    if (getenv("RT_AMD_DEBUG"))
-      fprintf(stderr, "[rt_amd] band grid n=%d entries=%zu built on the device in %.1f ms\n", n, n_items,
-              std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count() * 1e3);
+    if ((rc = attach_band_grid(s, b.bands.size()))) return rc;
   }
   if ((rc = upload(s, leaves, &s->dev.leaves))) return rc;
   if ((rc = upload(s, xforms, &s->dev.xforms))) return rc;
@@ -2619,13 +2617,17 @@ static int scene_create_impl(const rt_scene_desc* d, int device, rt_scene* s) {
 }
 
 extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+  return rt_scene_create_with(desc, device, 0u, out);
+}
+
+extern "C" int rt_scene_create_with(const rt_scene_desc* desc, int device, uint32_t build_flags, rt_scene** out) {
   if (!desc || !out) return fail(RT_ERR_INVALID, "null argument");
   *out = nullptr;
   rt_scene* s = new (std::nothrow) rt_scene();
   if (!s) return fail(RT_ERR_NOMEM, "out of host memory");
   int rc;
   try {
-    rc = scene_create_impl(desc, device, s);
+    rc = scene_create_impl(desc, device, build_flags, s);
   } catch (const std::bad_alloc&) {
     rc = fail(RT_ERR_NOMEM, "out of host memory while building the scene");
   } catch (const std::length_error& e) {
@@ -2640,6 +2642,45 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     return rc;
   }
   *out = s;
+  return RT_OK;
+}
+
+// Builds the cones' direction index on the current device from the bands already uploaded and hangs it
+// on the scene (16-bit entries when the band numbers fit).
+static int attach_band_grid(rt_scene* s, size_t n_bands) {
+  s->dev.band_grid_n = 0;
+  s->dev.band_start = s->dev.band_items = nullptr;
+  s->dev.band_items16 = 0;
+  int n = 0;
+  uint32_t *d_start = nullptr, *d_items = nullptr;
+  size_t n_items = 0;
+  int rc = build_band_grid_device(s->dev.bands, n_bands, (size_t)1 << 30, &n, &d_start, &d_items, &n_items);
+  if (rc) return rc;
+  size_t item_bytes = (n_items + 1) * 4;
+  if (d_items && n_bands < 65536) {
+    uint16_t* small = nullptr;
+    if ((rc = compress_band_items_u16(d_items, n_items, &small))) {
+      (void)hipFree(d_items);
+      if (d_start) (void)hipFree(d_start);
+      return rc;
+    }
+    d_items = reinterpret_cast<uint32_t*>(small);
+    item_bytes = (n_items + 2) * 2;
+    s->dev.band_items16 = 1;
+  }
+  s->dev.band_grid_n = n;
+  s->dev.band_start = d_start;
+  s->dev.band_items = d_items;
+  if (d_start) {
+    s->allocs.push_back(rt_scene::Alloc{d_start, ((size_t)3 * n * n + 1) * 4, offsetof(SceneDev, band_start)});
+    s->scene_bytes += ((size_t)3 * n * n + 1) * 4;
+  }
+  if (d_items) {
+    s->allocs.push_back(rt_scene::Alloc{d_items, item_bytes, offsetof(SceneDev, band_items)});
+    s->scene_bytes += item_bytes;
+  }
+  if (getenv("RT_AMD_DEBUG"))
+    fprintf(stderr, "[rt_amd] band grid n=%d entries=%zu (%d-bit) built on the device\n", n, n_items, s->dev.band_items16 ? 16 : 32);
   return RT_OK;
 }
 
@@ -2818,23 +2859,7 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
           s->allocs.erase(s->allocs.begin() + (long)k);
           break;
         }
-    s->dev.band_start = s->dev.band_items = nullptr;
-    s->dev.band_grid_n = 0;
-    int n = 0;
-    uint32_t *d_start = nullptr, *d_items = nullptr;
-    size_t n_items = 0;
-    if ((rc = build_band_grid_device(s->dev.bands, bands.size(), (size_t)1 << 30, &n, &d_start, &d_items, &n_items))) return rc;
-    s->dev.band_grid_n = n;
-    s->dev.band_start = d_start;
-    s->dev.band_items = d_items;
-    if (d_start) {
-      s->allocs.push_back(rt_scene::Alloc{d_start, ((size_t)3 * n * n + 1) * 4, RT_FIELD(band_start)});
-      s->scene_bytes += ((size_t)3 * n * n + 1) * 4;
-    }
-    if (d_items) {
-      s->allocs.push_back(rt_scene::Alloc{d_items, (n_items + 1) * 4, RT_FIELD(band_items)});
-      s->scene_bytes += (n_items + 1) * 4;
-    }
+    if ((rc = attach_band_grid(s, bands.size()))) return rc;
   }
   // ---- the hierarchy keeps its shape and gets new boxes
   if (H.n_nodes > 0) {
@@ -3088,6 +3113,13 @@ extern "C" void* rt_host_alloc(uint64_t bytes) {
 
 extern "C" void rt_host_free(void* p) {
   if (p) (void)hipHostFree(p);
+}
+
+extern "C" int rt_scene_build_info(const rt_scene* s, uint64_t* device_builds, double* device_build_seconds) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  if (device_builds) *device_builds = s->device_builds;
+  if (device_build_seconds) *device_build_seconds = s->device_build_seconds;
+  return RT_OK;
 }
 
 extern "C" int rt_scene_footprint(const rt_scene* s, uint64_t* scene_bytes, double* build_seconds) {

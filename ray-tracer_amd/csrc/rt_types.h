@@ -185,7 +185,7 @@ struct SceneDev {
   const ConeBandF32* bands32;  // first pass of that filter
   const QuadPrim* band_prims;
   const uint32_t* band_start;  // direction grid over bands (band_grid.h), null when band_grid_n == 0
-  const uint32_t* band_items;
+  const uint32_t* band_items;  // the cells' entries: 32-bit band indices, or 16-bit ones when band_items16 is set
   const CsgRoot* csg_roots;
   const CsgNode* csg_nodes;
   const CsgLeaf* csg_leaves;
@@ -205,6 +205,8 @@ struct SceneDev {
   int32_t band_grid_n;
   int32_t n_csg_unbounded;
   int32_t n_inline_planes;
+  int32_t band_items16;  // 1: band_items holds uint16_t entries (scenes of fewer than 65536 bounded cones)
+  int32_t pad;
   InlinePlane inline_planes[MAX_INLINE_PLANES];
   double light_intensity[3];
   double light_position[3];

@@ -1,0 +1,131 @@
+"""The acceleration structure built on the GPU (bvh_device.hip: Morton order, binary radix tree, collapse
+to the 4-wide layout) against the one the host builds (binned SAH): both are conservative hierarchies over
+the same shapes, so every image, hit leaf and ray count must be the same, bit for bit."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, GOLDEN)
+
+
+class builder:
+    """Chooses the builder of the scenes created inside the block (the library reads the environment per scene)."""
+
+    def __init__(self, device, min_items=2):
+        self.env = {"RT_AMD_DEVICE_BVH": "1" if device else "0", "RT_AMD_DEVICE_BVH_MIN": str(min_items)}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def both(pkg, text, size=None):
+    out = []
+    for device in (False, True):
+        with builder(device):
+            s = pkg.Scene(text, ROOT, device=0)
+        if size:
+            s.set_canvas(*size)
+        out.append((s, s.render(), s.footprint()))
+    return out
+
+
+def same(a, b):
+    (ra, sa), (rb, sb) = a, b
+    assert np.array_equal(ra["hit_leaf"], rb["hit_leaf"])
+    assert np.array_equal(ra["rgb64"], rb["rgb64"], equal_nan=True) and np.array_equal(ra["rgb8"], rb["rgb8"])
+    assert (sa.primary, sa.shadow, sa.reflect, sa.refract) == (sb.primary, sb.shadow, sb.reflect, sb.refract)
+
+
+@pytest.mark.parametrize("name", ["example", "egg", "glass", "pattern", "teapot", "allprims", "csg", "heightfield", "primitives"])
+def test_images_do_not_depend_on_the_builder(pkg, name, tmp_path):
+    size = None
+    if name in ("allprims", "csg"):
+        text = open(os.path.join(GOLDEN, name + ".json")).read()
+    elif name in ("heightfield", "primitives"):
+        import make_golden
+        text = open(make_golden.synthetic_scene(name, str(tmp_path))).read()
+    else:
+        text = open(os.path.join(ROOT, "scenes", name + ".json")).read()
+        size = (128, 72)
+    (host, r_host, f_host), (dev, r_dev, f_dev) = both(pkg, text, size)
+    same(r_host, r_dev)
+    assert f_host["device_builds"] == 0
+    if host.info()["leaves"] >= 4:  # a subtree of two items or more exists
+        assert f_dev["device_builds"] >= 1
+    rays = np.random.default_rng(4).uniform(-1, 1, (500, 6))
+    rays[:, :3] *= 8.0
+    rays[:, 3:] /= np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+    ca, la, _ = host.color_at(rays)
+    cb, lb, _ = dev.color_at(rays)
+    assert np.array_equal(la, lb) and np.array_equal(ca, cb, equal_nan=True)
+    assert np.array_equal(host.is_shadowed(rays[:, :3]), dev.is_shadowed(rays[:, :3]))
+
+
+def test_crowd_with_groups_built_on_the_device(pkg, tmp_path):
+    """Several hundred primitives, half of them in nested transformed groups: gates as items of the device build."""
+    import scenegen
+    path, n = scenegen.primitives(str(tmp_path), count=400, width=128, height=72, name="crowd")
+    scene = json.load(open(path))
+    shapes = scene["shapes"]
+    groups = []
+    for k in range(0, 200, 25):
+        inner = {"ty": "group", "transform": scenegen.translation(0.5, 0.0, -0.5), "children": shapes[k + 10:k + 25]}
+        groups.append({"ty": "group", "children": shapes[k:k + 10] + [inner]})
+    scene["shapes"] = groups + shapes[200:]
+    (host, r_host, _), (dev, r_dev, f_dev) = both(pkg, json.dumps(scene))
+    same(r_host, r_dev)
+    assert f_dev["device_builds"] >= 9
+
+
+def test_a_million_triangles_build_in_milliseconds(pkg, tmp_path):
+    import scenegen
+    path, tris = scenegen.heightfield(str(tmp_path), cells=708, name="hf_device")
+    assert tris == 1002528
+    text = open(path).read()
+    with builder(True, min_items=2048):
+        pkg.Scene(open(os.path.join(ROOT, "scenes", "teapot.json")).read(), ROOT, device=0)  # loads the builder's kernels
+        dev = pkg.Scene(text, ROOT, device=0)
+    f = dev.footprint()
+    print("device build of 1M triangles: %.2f ms in %d build(s); whole acceleration-structure phase %.1f ms" % (
+        f["device_build_seconds"] * 1e3, f["device_builds"], f["build_seconds"] * 1e3))
+    assert f["device_builds"] >= 1
+    assert f["device_build_seconds"] < 0.020
+    dev.set_canvas(960, 540)
+    r_dev = dev.render(rgb64=False)
+    with builder(False):
+        host = pkg.Scene(text, ROOT, device=0)
+    host.set_canvas(960, 540)
+    r_host = host.render(rgb64=False)
+    assert np.array_equal(r_dev[0]["hit_leaf"], r_host[0]["hit_leaf"]) and np.array_equal(r_dev[0]["rgb8"], r_host[0]["rgb8"])
+    assert r_dev[1].shadow == r_host[1].shadow
+
+
+def test_a_device_built_scene_is_updated_in_place(pkg):
+    import scenegen
+    text = open(os.path.join(GOLDEN, "allprims.json")).read()
+    scene = json.loads(text)
+    with builder(True):
+        moving = pkg.Scene(text, ROOT, device=0)
+    moving.render()
+    m = scenegen.matmul(scenegen.translation(-3.0, 0.5, 0.5), scenegen.rot_y(0.9))
+    scene["shapes"][1]["transform"] = list(m)
+    moving.set_transform([1], m)
+    moving.update()
+    with builder(False):
+        fresh = pkg.Scene(json.dumps(scene), ROOT, device=0)
+    same(moving.render(), fresh.render())
