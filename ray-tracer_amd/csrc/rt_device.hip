@@ -645,7 +645,7 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
       m = intersect_quadric(q.type, q.closed, q.minimum, q.maximum, quad_ray<true>(S, q, ray), t);
     }
     for (int k = 0; k < m; k++) {
-      if (!(t[k] == t[k]) || n >= CSG_MAX_HITS) continue;  // NaN never orders (the reference's sort would panic)
+      if (!(t[k] == t[k]) || n >= S.csg_hits) continue;  // NaN never orders (the reference's sort would panic)
       int e = n;
       while (e > 0 && get_t(e - 1) > t[k]) {  // stable: equal t stays behind earlier leaves
         put(e, get_t(e - 1), get_who(e - 1));
@@ -656,12 +656,13 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
     }
   }
   if (n == 0) return;
-  uint32_t alive = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+  static_assert(CSG_MAX_HITS <= 64, "one bit of `alive` per list entry");
+  unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
   for (int c = (int)R.n_nodes - 1; c >= 0; c--) {  // children carry larger indices than their parents
     const int op = S.csg_nodes[R.first_node + c].op;
     bool inl = false, inr = false;
     for (int e = 0; e < n; e++) {
-      if (!((alive >> e) & 1u)) continue;
+      if (!((alive >> e) & 1ull)) continue;
       const CsgLeaf& L = S.csg_leaves[R.first_leaf + get_who(e)];
       int a = L.node, level = 0;
       while (a > c) {
@@ -676,7 +677,7 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
       else allowed = lhit ? !inr : inl;
       if (lhit) inl = !inl;
       else inr = !inr;
-      if (!allowed) alive &= ~(1u << e);
+      if (!allowed) alive &= ~(1ull << e);
     }
   }
   if (!alive) return;
@@ -684,7 +685,7 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
     double t[4];
     int m = 0;
     for (int e = 0; e < n; e++)
-      if (((alive >> e) & 1u) && get_who(e) == j && m < 4) t[m++] = get_t(e);
+      if (((alive >> e) & 1ull) && get_who(e) == j && m < 4) t[m++] = get_t(e);
     if (!m) continue;
     const CsgLeaf L = S.csg_leaves[R.first_leaf + j];
     const uint32_t idx = L.ref & MAX_RUN_FIRST;
@@ -1249,7 +1250,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
                  uint32_t tiles_x, ImageOut img, const uint32_t* queue_counts, uint32_t segcap) {
   __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
   LdsStack<STACK, BLOCK, CSG, UNIFORM> st;
-  extern __shared__ uint32_t csg_lds[];  // CSG_MAX_HITS * 3 * BLOCK words when the scene has CSG operators, else nothing
+  extern __shared__ uint32_t csg_lds[];  // SceneDev::csg_hits * 3 * BLOCK words when the scene has CSG operators, else nothing
   st.init(lds, CSG ? csg_lds : nullptr);
 #ifdef RT_STAMPS
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
@@ -1577,7 +1578,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect(SceneDev S, GenView g, uint
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   LdsStack<STACK, BLOCK, CSG> st;
-  extern __shared__ uint32_t csg_lds[];  // CSG_MAX_HITS * 3 * BLOCK words when the scene has CSG operators, else nothing
+  extern __shared__ uint32_t csg_lds[];  // SceneDev::csg_hits * 3 * BLOCK words when the scene has CSG operators, else nothing
   st.init(lds, CSG ? csg_lds : nullptr);
   Counters cnt{};
   ClosestQuery Q;
@@ -1595,7 +1596,7 @@ __global__ void __launch_bounds__(BLOCK) k_points_shadowed(SceneDev S, uint32_t 
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   LdsStack<STACK, BLOCK, CSG> st;
-  extern __shared__ uint32_t csg_lds[];  // CSG_MAX_HITS * 3 * BLOCK words when the scene has CSG operators, else nothing
+  extern __shared__ uint32_t csg_lds[];  // SceneDev::csg_hits * 3 * BLOCK words when the scene has CSG operators, else nothing
   st.init(lds, CSG ? csg_lds : nullptr);
   Counters cnt{};
   V3 p = v3(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]);
@@ -2029,6 +2030,7 @@ struct SceneBuild {
   std::vector<TriIsect> csg_tris;
   std::vector<uint32_t> csg_unbounded;
   std::vector<int> csg_root_of;            // operator index -> root index (for roots), else -1
+  int csg_hits = CSG_MIN_HITS;             // the longest hit list a root of this scene can produce
   std::vector<TriIsect> tri_src;
   std::vector<int> tri_xform;  // device xform index or -1 (identity)
   int stack_need = 1;
@@ -2124,7 +2126,8 @@ struct SceneBuild {
       }
       R.n_leaves = (uint32_t)csg_leaves.size() - R.first_leaf;
       if (possible > CSG_MAX_HITS)
-        throw std::length_error("a CSG operator tree whose shapes can yield more than 16 intersections per ray");
+        throw std::length_error("a CSG operator tree whose shapes can yield more than 60 intersections per ray");
+      csg_hits = std::max(csg_hits, possible);
       const uint32_t root_index = (uint32_t)csg_roots.size();
       csg_roots.push_back(R);
       if (R.n_leaves == 0) continue;
@@ -2526,6 +2529,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
   if ((rc = upload(s, b.csg_leaves, &s->dev.csg_leaves))) return rc;
   if ((rc = upload(s, b.csg_unbounded, &s->dev.csg_unbounded))) return rc;
   s->dev.n_csg_unbounded = (int32_t)b.csg_unbounded.size();
+  s->dev.csg_hits = b.csg_hits;
   if ((rc = upload(s, b.bands, &s->dev.bands))) return rc;
   {
     std::vector<ConeBandF32> bands32 = cone_bands_f32(b.bands);
@@ -3167,13 +3171,13 @@ struct GenLaunch {
   uint32_t segcap = 0;                     // (null: the rays are dense, n of them)
 };
 
-constexpr unsigned CSG_LDS_BYTES = CSG_MAX_HITS * 3 * BLOCK * sizeof(uint32_t);
+inline unsigned csg_lds_bytes(const rt_scene* s) { return (unsigned)s->dev.csg_hits * 3u * BLOCK * (unsigned)sizeof(uint32_t); }
 
 template <int STACK, bool COUNT, bool CSG, bool UNIFORM = false>
 void launch_generation_mode(rt_scene* s, int mode, const GenLaunch& a) {
   dim3 grid(blocks_for(a.n)), block(BLOCK);
   static const unsigned env_lds = getenv("RT_AMD_EXTRA_LDS") ? (unsigned)atoi(getenv("RT_AMD_EXTRA_LDS")) : 0u;
-  const unsigned extra_lds = (CSG ? CSG_LDS_BYTES : 0u) + env_lds;
+  const unsigned extra_lds = (CSG ? csg_lds_bytes(s) : 0u) + env_lds;
 #define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap
   switch (mode) {
     case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
@@ -3815,7 +3819,7 @@ extern "C" int rt_intersect_hit(rt_scene* s, uint64_t n, const double* rays6, do
   if (rc) return rc;
   dim3 grid(blocks_for(n)), block(BLOCK);
   if (s->has_csg)
-    hipLaunchKernelGGL((k_intersect<64, true>), grid, block, CSG_LDS_BYTES, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
+    hipLaunchKernelGGL((k_intersect<64, true>), grid, block, csg_lds_bytes(s), s->stream, s->dev, s->gens[0].view, (uint32_t)n);
   else if (pick_stack(s->stack_need) == STACK_SMALL)
     hipLaunchKernelGGL((k_intersect<STACK_SMALL, false>), grid, block, 0, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
   else
@@ -3843,7 +3847,7 @@ extern "C" int rt_is_shadowed(rt_scene* s, uint64_t n, const double* points3, ui
   HIP_TRY(hipMemcpyAsync(d_pts, points3, n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
   dim3 grid(blocks_for(n)), block(BLOCK);
   if (s->has_csg)
-    hipLaunchKernelGGL((k_points_shadowed<64, true>), grid, block, CSG_LDS_BYTES, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
+    hipLaunchKernelGGL((k_points_shadowed<64, true>), grid, block, csg_lds_bytes(s), s->stream, s->dev, (uint32_t)n, d_pts, d_out);
   else if (pick_stack(s->stack_need) == STACK_SMALL)
     hipLaunchKernelGGL((k_points_shadowed<STACK_SMALL, false>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
   else

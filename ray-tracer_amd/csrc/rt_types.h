@@ -111,8 +111,11 @@ static_assert(sizeof(Gate) == 192, "Gate layout");
 
 // CSG (reference src/shape.rs:1339-1354, src/intersect.rs:278-328).  A root is a maximal operator
 // tree; a ray that reaches it collects the intersections of all leaves below (at most
-// CSG_MAX_HITS), sorts them and runs every operator's filter, innermost first.
-constexpr int CSG_MAX_HITS = 16;
+// SceneDev::csg_hits, the most any root of the scene can yield: 2 per sphere or cube, 4 per cylinder or
+// cone, 1 per plane or triangle), sorts them and runs every operator's filter, innermost first.  The list
+// lives in LDS, 768 bytes per entry and wave, beside the 16 KB traversal stack: CSG_MAX_HITS entries fit
+// the 64 KB a workgroup may use.
+constexpr int CSG_MIN_HITS = 16, CSG_MAX_HITS = 60;
 struct CsgRoot {
   uint32_t first_leaf, n_leaves;  // into csg_leaves
   uint32_t first_node, n_nodes;   // into csg_nodes, parents before children
@@ -206,7 +209,7 @@ struct SceneDev {
   int32_t n_csg_unbounded;
   int32_t n_inline_planes;
   int32_t band_items16;  // 1: band_items holds uint16_t entries (scenes of fewer than 65536 bounded cones)
-  int32_t pad;
+  int32_t csg_hits;      // entries of the per-ray CSG hit list (CSG_MIN_HITS .. CSG_MAX_HITS)
   InlinePlane inline_planes[MAX_INLINE_PLANES];
   double light_intensity[3];
   double light_position[3];

@@ -37,6 +37,8 @@ pub const RT_FLAG_COUNTERS: u32 = 1;
 pub const RT_FLAG_ASYNC: u32 = 2;
 pub const RT_FLAG_COMPACT: u32 = 4;
 pub const RT_FLAG_BANDS: u32 = 8;
+// build_flags of rt_scene_create_with
+pub const RT_BUILD_DEVICE: u32 = 1;
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct rt_xform { pub ray_inv: [f64; 16], pub full_inv: [f64; 16], pub fwd: [f64; 16] }
@@ -108,6 +110,9 @@ extern "C" {
     pub fn rt_device_count() -> c_int;
     pub fn rt_scene_create(desc: *const rt_scene_desc, device: c_int, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene);
+    pub fn rt_scene_create_with(desc: *const rt_scene_desc, device: c_int, build_flags: u32, out: *mut *mut rt_scene) -> c_int;
+    pub fn rt_scene_build_info(scene: *const rt_scene, device_builds: *mut u64, device_build_seconds: *mut f64) -> c_int;
+    pub fn rt_scene_update(scene: *mut rt_scene, desc: *const rt_scene_desc) -> c_int;
     pub fn rt_scene_clone(scene: *const rt_scene, device: c_int, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_footprint(scene: *const rt_scene, scene_bytes: *mut u64, build_seconds: *mut f64) -> c_int;
     pub fn rt_render(scene: *mut rt_scene, camera: *const rt_camera, part: c_int, n_parts: c_int, flags: u32,

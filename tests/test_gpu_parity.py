@@ -282,13 +282,56 @@ def test_csg_operators_match_the_oracle_ray_by_ray(pkg, root):
             assert np.abs(rgb - want).max() <= 1e-9 and [st.primary, st.shadow, st.reflect, st.refract] == counts
 
 
+def test_three_level_csg_of_capped_cylinders(pkg, root):
+    """Eight capped cylinders under seven operators: up to 32 intersections per ray in one hit list (the
+    reference has no limit, src/shape.rs:1339-1354; the list here holds 60).  Image and random rays against
+    the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from scenegen import matmul, rot_x, rot_y, rot_z, scaling, translation
+
+    def cyl(t, r, s, **mat):
+        d = {"ty": "capped_cylinder", "transform": matmul(translation(*t), matmul(r, scaling(*s)))}
+        d["material"] = dict({"color": [0.8, 0.5, 0.2]}, **mat)
+        return d
+
+    half = 1.5707963267948966
+    a = {"ty": "difference", "children": [cyl((0, 0, 0), rot_x(0), (1.0, 1.2, 1.0)), cyl((0, 0, 0), rot_x(half), (0.5, 1.6, 0.5))]}
+    b = {"ty": "union", "children": [cyl((0.3, 0, 0), rot_z(half), (0.4, 1.8, 0.4), color=[0.2, 0.7, 0.9]),
+                                     cyl((0, 0.2, 0.1), rot_z(0.7), (0.3, 1.7, 0.3), reflective=0.3)]}
+    c = {"ty": "intersection", "children": [cyl((0, 0, 0), rot_y(0.3), (1.3, 0.9, 1.3)), cyl((0.2, 0, 0), rot_x(0.4), (1.1, 1.5, 1.1))]}
+    e = {"ty": "difference", "children": [cyl((0, 0, 0), rot_x(0), (0.8, 2.0, 0.8), transparency=0.6, refractive_index=1.3),
+                                          cyl((0, 0.5, 0), rot_x(0), (0.45, 2.5, 0.45))]}
+    tree = {"ty": "union", "transform": matmul(translation(0, 0.3, 0), rot_y(0.5)),
+            "children": [{"ty": "difference", "children": [a, b]}, {"ty": "union", "transform": translation(2.6, 0, 0.5), "children": [c, e]}]}
+    base = json.load(open(os.path.join(root, "scenes", "example.json")))
+    text = json.dumps(dict(base, canvas_width=160, canvas_height=90, shapes=[tree, base["shapes"][1]]))
+    gpu, cpu = pkg.Scene(text, root, device=0), orc.OracleScene(text, root)
+    out, st = gpu.render()
+    want = cpu.render(jobs=8)
+    assert len(np.unique(want["hit_leaf"])) >= 8  # most of the cylinders are seen
+    compare_images(out, st, want, "csg of eight capped cylinders")
+    rays = random_rays(800, 3, spread=5.0)
+    t, leaf = gpu.intersect_hit(rays)
+    wt, wleaf = cpu.intersect_hit(rays)
+    assert np.array_equal(leaf, wleaf)
+    assert np.allclose(t[leaf >= 0], wt[leaf >= 0], rtol=1e-12)
+    rgb, _, st2 = gpu.color_at(rays)
+    wrgb, _, counts = cpu.color_at(rays)
+    assert np.abs(rgb - wrgb).max() <= 1e-9 and [st2.primary, st2.shadow, st2.reflect, st2.refract] == counts
+
+
 def test_csg_with_too_many_possible_hits_is_refused(pkg, root):
     cyl = {"ty": "capped_cylinder"}
-    tree = {"ty": "union", "children": [{"ty": "union", "children": [cyl, cyl]},
-                                        {"ty": "union", "children": [{"ty": "union", "children": [cyl, cyl]}, {"ty": "sphere"}]}]}
+
+    def pair(x):
+        return {"ty": "union", "children": [x, x]}
+
+    tree = pair(pair(pair(pair(cyl))))  # 16 cylinders: 64 possible intersections per ray, the list holds 60
     with pytest.raises(pkg.RtError) as e:
-        _csg_world(pkg, root, [tree])  # 4 x 4 + 2 = 18 possible intersections per ray
-    assert e.value.status == -2
+        _csg_world(pkg, root, [tree])
+    assert e.value.status == -2 and "60" in e.value.message
+    _csg_world(pkg, root, [{"ty": "union", "children": [pair(pair(pair(cyl))), pair(pair(cyl))]}])  # 48: accepted
 
 
 def test_parallel_render_writes_the_reference_ppm(pkg, root, tmp_path):

@@ -23,6 +23,16 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(host, n)
 
 
+def test_rust_binding_declares_every_export():
+    """rust/src/ffi.rs (not compiled here: no Rust toolchain) names every function the header declares."""
+    header = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    ffi = open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read()
+    names = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", header))
+    declared = set(re.findall(r"pub fn (rt_[a-z_0-9]+)\(", ffi))
+    assert names - declared == set(), "missing in ffi.rs: %s" % sorted(names - declared)
+    assert declared - names == set(), "ffi.rs declares what the header does not: %s" % sorted(declared - names)
+
+
 def test_header_is_plain_c99(tmp_path):
     """include/rt_amd.h compiles as C99 with no extensions; the smoke program that uses it was built the same way."""
     import subprocess
