@@ -7,8 +7,9 @@ exactly those bands over its own PCIe link into one page-locked host frame; ther
 exchange.  `python bench.py --gpus N` is one process that drives N GPUs with one native worker thread
 per GPU (the host library's FrameLoop, the many-frame form of parallel_render, src/parallel.rs:183-204).
 With fewer GPUs than N the parts are dealt round-robin over the GPUs there are (a rehearsal; the line
-says so).  Launched by torch.distributed.run with one rank per GPU (WORLD_SIZE > 1) the same frames are
-gathered on rank 0 with an RCCL gather instead (bench_ranks).
+says so).  Launched by torch.distributed.run with one rank per GPU (WORLD_SIZE > 1) every rank runs the same loop for
+its own part and the ranks assemble the frames in one shared-memory ring (bench_ranks; --rccl-gather selects
+the variant that gathers the parts on rank 0 with RCCL instead).
 
 A ray is one World::intersect query of the reference algorithm (primary, shadow, reflection,
 refraction).  The scene stays resident in HBM; scene load and the BVH build are outside the timed
@@ -226,9 +227,141 @@ def bench_single_process(args):
 
 
 def bench_ranks(args, world):
-    """One rank per GPU under torch.distributed: every rank renders its interleaved 32x32 tiles in the
-    compact layout, rank 0 gathers them (one RCCL gather per BUCKET frames) and copies every frame to
-    pinned host memory."""
+    """One rank per GPU under torch.distributed, no data-path collective: every rank runs the host library's
+    FrameLoop for its own part of the frame (bands of 32 pixel rows, part = rank) and copies exactly those
+    bands over its own GPU's PCIe link into one ring of frames in shared memory that every rank has mapped
+    and page-locked.  torch.distributed carries only the barriers around the timed region, the MAX over the
+    ranks' times and the sums of the ray counts."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RT_BENCH_BACKEND=gloo rehearses the multi-rank path on a machine with fewer GPUs than ranks
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    have = max(1, torch.cuda.device_count())
+    dev_index = local_rank % have if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+        red_device = device
+    else:
+        dist.init_process_group(backend)
+        red_device = torch.device("cpu")
+
+    pkg = load_package()
+    W, H = args.width, args.height
+    # The frames are assembled in one shared-memory ring when the machine can page-lock a mapping the caller owns
+    # (rt_host_register); where it cannot, every rank keeps its bands in a page-locked ring of its own and the
+    # shared mapping serves only to put the last frame together for the checksum, after the timed region.
+    name = ["rt_amd_bench_%d_%d" % (os.getpid(), int(time.time()))] if rank == 0 else [None]
+    dist.broadcast_object_list(name, src=0)
+    shared = pkg.bindings.SharedFrameRing(name[0], W, H, DEPTH, create=True, register=False) if rank == 0 else None
+    dist.barrier()
+    if rank != 0:
+        shared = pkg.bindings.SharedFrameRing(name[0], W, H, DEPTH, create=False, register=False)
+    pinned = [0]
+    if os.environ.get("RT_BENCH_PRIVATE_RINGS", "0") != "1":
+        pinned[0] = 1 if shared.register() else 0
+    flags = [None] * world
+    dist.all_gather_object(flags, pinned[0])
+    assembled_by_dma = all(flags)
+    if assembled_by_dma:
+        ring = shared
+    else:
+        shared.unregister()
+        ring = pkg.bindings.HostFrameRing(W, H, DEPTH)
+    t_load = time.perf_counter()
+    scene = pkg.Scene.from_file(args.scene, base_dir=ROOT, device=None)
+    scene.set_canvas(W, H)
+    loop = scene.frame_loop([dev_index], depth=DEPTH, first_part=rank, total_parts=world, ring=ring)
+    load_s = time.perf_counter() - t_load
+    info, linfo = scene.info(), loop.info()
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def all_sum(d):
+        keys = sorted(d)
+        t = torch.tensor([float(d[k]) for k in keys], dtype=torch.float64, device=red_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return {k: float(v) for k, v in zip(keys, t.tolist())}
+
+    def timed_loop(to_host):
+        loop.run(0, PRIMING + args.warmup, to_host)  # untimed
+        sync()
+        t0 = time.perf_counter()
+        _, stats = loop.run(0, args.steps, to_host)  # returns when this rank's frames are rendered and copied
+        sync()
+        dt = time.perf_counter() - t0
+        t_max = torch.tensor([dt], dtype=torch.float64, device=red_device)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return float(t_max.item()), stats
+
+    host_s, host_stats = timed_loop(True)
+    last = (args.steps - 1) % DEPTH
+    if not assembled_by_dma:  # outside the timed region: the ranks' bands of the last frame put together for the checksum
+        for y0, y1 in pkg.tiles.part_bands(H, rank, world):
+            shared.frame(last)[y0:y1] = ring.frame(last)[y0:y1]
+        sync()
+    sha = hashlib.sha256(shared.frame(last).tobytes()).hexdigest() if rank == 0 else None
+    sync()  # nobody renders over the frame while rank 0 reads it
+    hbm_s = None if args.no_hbm_leg else timed_loop(False)[0]
+    lone_mine = sum_stats(loop.blocking_frames(10, False))
+    counted_mine = sum_stats(loop.blocking_frames(1, True))
+    piped_mine = sum_stats(host_stats)
+    piped = all_sum(piped_mine)
+    rays_per_frame = (piped["primary"] + piped["shadow"] + piped["reflect"] + piped["refract"]) / args.steps
+    roofline = roofline_of(counted_mine, lone_mine, piped_mine, linfo["scene_bytes"], host_s / args.steps, 1)
+    roofline["scope"] = "rank 0's part of the frame"
+    counted = all_sum(counted_mine)
+    flops_frame = ((counted["node_visits"] + counted["shadow_node_visits"]) * SURVEY["node"]
+                   + (counted["tri_tests"] + counted["shadow_tri_tests"]) * SURVEY["tri"]
+                   + (counted["quadric_tests"] + counted["shadow_quadric_tests"]) * SURVEY["quad"] + counted["shadow"] * SURVEY["hit"])
+    roofline["frac_per_frame_period"] = flops_frame / (host_s / args.steps) / (FP64_VALU_PEAK * world)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "rays/sec (node) on scenes/teapot.json at 1080p",
+            "value": rays_per_frame * args.steps / host_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": host_s / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "%s at %dx%d: generated models/teapot.obj (%d smooth triangles in %d groups) + floor plane, "
+                            "one point light, recursion depth 5" % (os.path.relpath(args.scene, ROOT), W, H, info["triangles"], info["gates"]),
+                "rays_per_frame": rays_per_frame,
+                "timed_region": "ray generation to the finished frame in page-locked host memory: " + (
+                    "one shared-memory frame that every rank fills with its own bands by DMA" if assembled_by_dma else
+                    "every rank's bands in a page-locked ring of its own (this machine's hipHostRegister refuses to page-lock "
+                    "a shared mapping, so the bands are not assembled in one mapping inside the timed region)"),
+                "frame_assembled_by_dma_in_shared_memory": assembled_by_dma,
+                "parallelism": "one rank per GPU, %d parts = bands of 32 pixel rows dealt round-robin, scene replicated, each "
+                               "rank copies its bands over its own PCIe link into the shared frame; no collective on the "
+                               "data path" % world,
+                "rehearsal": backend != "nccl"},
+            "roofline": roofline, "cpu_baseline": None,
+            "frames_left_in_hbm": None if hbm_s is None else {
+                "value": rays_per_frame * args.steps / hbm_s, "unit": "rays/s", "ms_per_step": hbm_s / args.steps * 1e3,
+                "note": "the same loop without the copies to the host (not the metric's timed region)"},
+            "PCIe_GBps": W * H * 3 * args.steps / host_s / 1e9,
+            "pipeline": {"frames_in_flight_per_gpu": DEPTH, "untimed_priming_frames": PRIMING},
+            "frame_sha256": sha,
+            "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": linfo["build_seconds"], "scene_bytes": linfo["scene_bytes"]},
+        }))
+    loop.close()
+    sync()
+    if ring is not shared:
+        ring.close()
+    shared.close()
+    dist.destroy_process_group()
+
+
+def bench_ranks_rccl_gather(args, world):
+    """The variant with a collective (--rccl-gather): every rank renders its interleaved 32x32 tiles in the
+    compact layout, rank 0 gathers them (one RCCL gather per BUCKET frames) into whole frames in its HBM and
+    copies every frame to pinned host memory, so every frame crosses rank 0's PCIe link."""
     import torch
     import torch.distributed as dist
 
@@ -363,6 +496,9 @@ def main():
     ap.add_argument("--hbm-only", action="store_true",
                     help="time only the loop that leaves the frames in HBM (for profiler runs: under rocprofv3 the runtime "
                          "turns the DMA copies to the host into copy kernels that share the GPU with the render kernel)")
+    ap.add_argument("--rccl-gather", action="store_true",
+                    help="under a launcher with one rank per GPU: gather the parts on rank 0 with RCCL instead of "
+                         "letting every rank copy its bands into the shared host frame")
     ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline renders every n-th pixel of every n-th row")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -371,7 +507,7 @@ def main():
     if world > 1:
         if world != args.gpus:
             raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world))
-        bench_ranks(args, world)
+        (bench_ranks_rccl_gather if args.rccl_gather else bench_ranks)(args, world)
     else:
         bench_single_process(args)
 

@@ -268,13 +268,13 @@ int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, u
               uint8_t* rgb8_dev, double* rgb64_dev, int32_t* hit_leaf_dev, rt_stats* stats);
 
 /* Frames of a render loop, back to back.  With RT_FLAG_ASYNC, rt_render enqueues the frame on the
- * scene's stream and returns at once (stats is not written); at most four frames are in flight, a
- * fifth call waits for the oldest.  A scene whose materials spawn reflection or refraction rays
+ * scene's stream and returns at once (stats is not written); at most eight frames are in flight, a
+ * ninth call waits for the oldest.  A scene whose materials spawn reflection or refraction rays
  * needs the host between generations, so there the call blocks as usual (its counts still go to rt_scene_wait).
  * rt_scene_wait blocks until every enqueued frame is complete and returns the sums of their ray
  * counts, kernel time and kernel launches since the previous wait (render_ms is not filled).
- * Asynchronous frames alternate between two streams of the scene.  rt_download / rt_download_2d without
- * an after_stream wait for both; every blocking entry point of the scene first collects the frames in
+ * Asynchronous frames go round-robin to three streams of the scene.  rt_download / rt_download_2d without
+ * an after_stream wait for all of them; every blocking entry point of the scene first collects the frames in
  * flight.  Work a caller enqueues on streams of its own (and rt_ppm_encode, which runs on the null
  * stream) is not ordered against frames in flight: call rt_scene_wait first, or order the stream after
  * rt_scene_stream.  The reference renders one frame per process (src/main.rs:71); this pair has no
@@ -282,13 +282,13 @@ int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, u
 int rt_scene_wait(rt_scene* scene, rt_stats* total);
 
 /* The HIP stream (hipStream_t) the most recent frame was enqueued on, so that a caller can order
- * its own streams after it (hipStreamWaitEvent).  Asynchronous frames alternate between two
+ * its own streams after it (hipStreamWaitEvent).  Asynchronous frames go round-robin to three
  * streams, so ask again after every rt_render. */
 int rt_scene_stream(rt_scene* scene, void** hip_stream);
 
 /* Copies `bytes` from device memory to pinned (page-locked) host memory on the scene's copy
  * stream (a DMA transfer that runs beside the next frame's kernel).  The copy is enqueued; it starts
- * after everything enqueued so far on after_stream (a hipStream_t; NULL = both render streams of the
+ * after everything enqueued so far on after_stream (a hipStream_t; NULL = every render stream of the
  * scene) and is complete after rt_scene_wait or after the copy stream
  * (rt_scene_copy_stream) has drained.  The caller keeps src_dev and dst_host untouched until then.
  * Replaces the per-pixel channel receive of the reference's canvas (src/parallel.rs:196-200). */
@@ -313,6 +313,11 @@ int rt_copy_wait(rt_scene* scene, uint32_t slot);
  * in it are filled by DMA at full PCIe speed.  The reference's canvas is a plain Vec (src/canvas.rs:22-28). */
 void* rt_host_alloc(uint64_t bytes);
 void rt_host_free(void* p);
+/* Page-locks memory the caller owns (the canvas of src/canvas.rs:22-28 where it lies, or a shared-memory
+ * mapping in which the processes of several GPUs assemble one frame, each over its own PCIe link) so that
+ * rt_download fills it by DMA like memory from rt_host_alloc.  Unregister before the memory is released. */
+int rt_host_register(void* p, uint64_t bytes);
+int rt_host_unregister(void* p);
 
 /* Device memory on `device` for the frames rt_render writes (zero-filled), for hosts that do not link a
  * GPU runtime of their own.  The reference's canvas is a plain Vec (src/canvas.rs:22-28). */

@@ -94,6 +94,12 @@ def libraries():
     amd.rt_scene_copy_stream.argtypes = [vp, C.POINTER(vp)]
     amd.rt_download.argtypes = [vp, vp, vp, u64, vp]
     amd.rt_download_2d.argtypes = [vp, vp, vp, u64, u64, u64, vp]
+    amd.rt_host_alloc.argtypes = [u64]
+    amd.rt_host_alloc.restype = vp
+    amd.rt_host_free.argtypes = [vp]
+    amd.rt_host_free.restype = None
+    amd.rt_host_register.argtypes = [vp, u64]
+    amd.rt_host_unregister.argtypes = [vp]
     amd.rt_render_host.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
     amd.rt_ray_for_pixel.argtypes = [vp, C.POINTER(RtCamera), u64, vp, vp]
     amd.rt_color_at.argtypes = [vp, u64, vp, i32, u32, vp, vp, C.POINTER(RtStats)]
@@ -127,6 +133,7 @@ def libraries():
     host.rth_canvas_pixels.restype = dp
     host.rth_canvas_save.argtypes = [vp, C.c_char_p]
     host.rth_frame_loop_new.argtypes = [vp, u64, C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
+    host.rth_frame_loop_new_shared.argtypes = [vp, u64, C.POINTER(C.c_int32), C.c_int32, u64, u64, vp, C.POINTER(vp)]
     host.rth_frame_loop_free.argtypes = [vp]
     host.rth_frame_loop_run.argtypes = [vp, u64, u64, C.c_int32, dp, C.POINTER(RtStats)]
     host.rth_frame_loop_blocking.argtypes = [vp, u64, C.c_int32, C.POINTER(RtStats)]
@@ -241,19 +248,135 @@ class Canvas:
             raise RtError(rc, self._host.rth_last_error().decode())
 
 
+class SharedFrameRing:
+    """`depth` frames of width x height RGB8 in a POSIX shared-memory file that every process of a job maps
+    and page-locks (rt_host_register), so that each GPU's process copies its own bands of the frame over its
+    own PCIe link and the finished frame lies in one place.  create=True makes (and at close removes) the file.
+    register=False leaves the memory pageable (host-only uses and tests without a GPU)."""
+
+    def __init__(self, name, width, height, depth, create, register=True):
+        import mmap
+        dev = libraries()[0] if register else None
+        self._dev = dev
+        self.width, self.height, self.depth = int(width), int(height), int(depth)
+        self.frame_bytes = self.width * self.height * 3
+        self.bytes = self.frame_bytes * self.depth
+        self.path = os.path.join("/dev/shm", name)
+        self._owner = bool(create)
+        fd = os.open(self.path, (os.O_CREAT | os.O_EXCL | os.O_RDWR) if create else os.O_RDWR, 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, self.bytes)
+            elif os.fstat(fd).st_size != self.bytes:
+                raise ValueError("shared frame ring %s has another size" % self.path)
+            self._map = mmap.mmap(fd, self.bytes)
+        finally:
+            os.close(fd)
+        self._view = (C.c_uint8 * self.bytes).from_buffer(self._map)
+        self.address = C.addressof(self._view)
+        self._registered = False
+        if register and not self.register():
+            msg = self._dev.rt_last_error().decode()
+            self.close()
+            raise RtError(-3, msg)
+
+    def register(self):
+        """Page-locks the mapping for DMA from the GPUs of this process; False when the machine refuses."""
+        if not self._registered:
+            if self._dev is None:
+                self._dev = libraries()[0]
+            self._registered = self._dev.rt_host_register(C.c_void_p(self.address), self.bytes) == 0
+        return self._registered
+
+    def unregister(self):
+        if self._registered:
+            self._dev.rt_host_unregister(C.c_void_p(self.address))
+            self._registered = False
+
+    def frame(self, slot):
+        """(H, W, 3) uint8 view of ring slot `slot`."""
+        a = np.frombuffer(self._view, dtype=np.uint8, count=self.frame_bytes, offset=slot * self.frame_bytes)
+        return a.reshape(self.height, self.width, 3)
+
+    def close(self):
+        if getattr(self, "_registered", False):
+            self.unregister()
+        if getattr(self, "_view", None) is not None:
+            self._view = None
+            try:
+                self._map.close()
+            except BufferError:
+                pass  # a view handed out by frame() is still alive; the mapping goes with it
+            self._map = None
+        if getattr(self, "_owner", False):
+            try:
+                os.unlink(self.path)
+            except FileNotFoundError:
+                pass
+            self._owner = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostFrameRing:
+    """`depth` frames of width x height RGB8 in page-locked memory of this process (rt_host_alloc): the ring a
+    process-per-GPU loop fills with its own bands where the machine cannot page-lock a shared mapping."""
+
+    def __init__(self, width, height, depth):
+        dev, _ = libraries()
+        self._dev = dev
+        self.width, self.height, self.depth = int(width), int(height), int(depth)
+        self.frame_bytes = self.width * self.height * 3
+        self.bytes = self.frame_bytes * self.depth
+        self.address = dev.rt_host_alloc(self.bytes)
+        if not self.address:
+            raise RtError(-2, "no page-locked host memory for the frame ring")
+        C.memset(self.address, 0, self.bytes)
+
+    def frame(self, slot):
+        buf = (C.c_uint8 * self.frame_bytes).from_address(self.address + slot * self.frame_bytes)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 3)
+
+    def close(self):
+        if getattr(self, "address", None):
+            self._dev.rt_host_free(C.c_void_p(self.address))
+            self.address = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FrameLoop:
     """The host library's render loop over several GPUs of this process (host/rt_host.hpp FrameLoop):
     one worker thread and one copy of the scene per part, each GPU copying its own bands of 32 pixel
-    rows into a ring of page-locked host frames shared by all parts."""
+    rows into a ring of page-locked host frames shared by all parts.
 
-    def __init__(self, scene, devices, depth=4):
+    With `ring` (a SharedFrameRing or HostFrameRing) the loop renders only parts first_part .. first_part + len(devices) - 1
+    of total_parts and assembles the frames in the ring: one process per GPU, no collective."""
+
+    def __init__(self, scene, devices, depth=4, first_part=0, total_parts=None, ring=None):
         _, self._host = libraries()
         self._scene = scene  # keeps the World alive
+        self._ring = ring    # and the shared mapping
         self.devices = [int(d) for d in devices]
         self.depth = depth
         arr = (C.c_int32 * len(self.devices))(*self.devices)
         h = C.c_void_p()
-        rc = self._host.rth_frame_loop_new(scene._h, len(self.devices), arr, depth, C.byref(h))
+        if ring is None and first_part == 0 and total_parts in (None, len(self.devices)):
+            rc = self._host.rth_frame_loop_new(scene._h, len(self.devices), arr, depth, C.byref(h))
+        else:
+            if ring is not None and (ring.depth < depth or (ring.width, ring.height) != (scene.camera().hsize, scene.camera().vsize)):
+                raise ValueError("the shared ring does not fit the loop's frames")
+            rc = self._host.rth_frame_loop_new_shared(scene._h, len(self.devices), arr, depth, int(first_part),
+                                                      int(total_parts or 0), C.c_void_p(ring.address if ring is not None else None),
+                                                      C.byref(h))
         if rc != 0:
             raise RtError(rc, self._host.rth_last_error().decode())
         self._l = h
@@ -476,9 +599,10 @@ class Scene:
             raise RtError(rc, self._host.rth_last_error().decode())
         return Canvas(_handle=h)
 
-    def frame_loop(self, devices, depth=4):
-        """parallel_render's workers kept alive over frames: part k of len(devices) on GPU devices[k]."""
-        return FrameLoop(self, devices, depth)
+    def frame_loop(self, devices, depth=4, first_part=0, total_parts=None, ring=None):
+        """parallel_render's workers kept alive over frames: part first_part + k of total_parts (default
+        len(devices)) on GPU devices[k]; frames assembled in `ring` (a SharedFrameRing) when given."""
+        return FrameLoop(self, devices, depth, first_part, total_parts, ring)
 
     # ---- batch forms of the reference's per-ray API
     def ray_for_pixel(self, xy):

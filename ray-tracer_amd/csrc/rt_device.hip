@@ -93,8 +93,10 @@ int rt_fail_message(int code, const char* msg) { return fail(code, msg ? msg : "
 #define HIP_TRY(expr)                                                                       \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
+    if (e_ != hipSuccess) {                                                                 \
+      (void)hipGetLastError(); /* reported here: a later launch check must not see it again */ \
       return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    }                                                                                       \
   } while (0)
 
 // ---------------------------------------------------------------------------
@@ -1738,10 +1740,20 @@ void carve(GenBuf& b) {
 struct rt_scene {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t frame_stream = nullptr;  // asynchronous frames alternate between stream and frame_stream
+  // Asynchronous frames go round-robin to `stream` and the first n_frame_streams - 1 of these.  Three
+  // render streams and the copy stream make four, the hardware queues a process has by default
+  // (GPU_MAX_HW_QUEUES): a fourth render stream shares a queue and measured no better than two.  A
+  // whole 1080p frame fills the GPU from one stream pair; a part of a frame (one GPU of several) is
+  // bound by its slowest waves, and a third kernel in flight cut its frame period by a quarter.
+  static constexpr int FRAME_STREAMS = 4;
+  hipStream_t frame_stream[FRAME_STREAMS - 1] = {nullptr, nullptr, nullptr};
+  int n_frame_streams = 3;
+  unsigned frame_seq = 0;
+  // work enqueued on stream / frame_stream[k] that the copy stream has not been ordered after
+  bool stream_used = true, frame_stream_used[FRAME_STREAMS - 1] = {false, false, false};
   hipStream_t last_stream = nullptr;   // where the most recent frame was enqueued
   hipStream_t copy_stream = nullptr;   // rt_download
-  hipEvent_t copy_order = nullptr, copy_order2 = nullptr;
+  hipEvent_t copy_order = nullptr, copy_order2[FRAME_STREAMS - 1] = {nullptr, nullptr, nullptr};
   static constexpr int COPY_FENCES = 8;
   hipEvent_t copy_fence[COPY_FENCES] = {};  // rt_copy_fence / rt_copy_wait
   bool copy_fence_set[COPY_FENCES] = {};
@@ -1787,7 +1799,7 @@ struct rt_scene {
     bool pending = false;
     uint64_t primary = 0;
   };
-  static constexpr int FRAME_SLOTS = 4;
+  static constexpr int FRAME_SLOTS = 8;
   FrameSlot slots[FRAME_SLOTS];
   int next_slot = 0;
   rt_stats async_total{};
@@ -1813,6 +1825,12 @@ struct rt_scene {
     bool updated = false;                   // every gate is tested since the first update
   } host;
 };
+
+// The scene's main stream for an enqueue; the copy stream is ordered after it at the next download.
+static inline hipStream_t main_stream(rt_scene* s) {
+  s->stream_used = true;
+  return s->stream;
+}
 
 namespace {
 
@@ -2255,7 +2273,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   (void)hipSetDevice(s->device);
   // frames may still run on either render stream and copies on the copy stream: drain all three
   // before any of the memory they use is released
-  for (hipStream_t st : {s->stream, s->frame_stream, s->copy_stream})
+  for (hipStream_t st : {s->stream, s->frame_stream[0], s->frame_stream[1], s->frame_stream[2], s->copy_stream})
     if (st) (void)hipStreamSynchronize(st);
   for (const rt_scene::Alloc& a : s->allocs) (void)hipFree(a.p);
   for (GenBuf& g : s->gens)
@@ -2282,13 +2300,15 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     (void)hipStreamDestroy(s->copy_stream);
   }
   if (s->copy_order) (void)hipEventDestroy(s->copy_order);
-  if (s->copy_order2) (void)hipEventDestroy(s->copy_order2);
+  for (hipEvent_t e : s->copy_order2)
+    if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->copy_fence)
     if (e) (void)hipEventDestroy(e);
-  if (s->frame_stream) {
-    (void)hipStreamSynchronize(s->frame_stream);
-    (void)hipStreamDestroy(s->frame_stream);
-  }
+  for (hipStream_t st : s->frame_stream)
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -2298,11 +2318,12 @@ static int scene_runtime_init(rt_scene* s, int device) {
   HIP_TRY(hipSetDevice(device));
   s->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&s->frame_stream, hipStreamNonBlocking));
+  for (hipStream_t& st : s->frame_stream) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  if (const char* e = getenv("RT_AMD_FRAME_STREAMS")) s->n_frame_streams = std::min(std::max(atoi(e), 1), (int)rt_scene::FRAME_STREAMS);
   s->last_stream = s->stream;
   HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&s->copy_order, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&s->copy_order2, hipEventDisableTiming));
+  for (hipEvent_t& e : s->copy_order2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (hipEvent_t& e : s->copy_fence) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_TRY(hipMalloc((void**)&s->d_counts, COUNT_WORDS * sizeof(uint32_t)));
   HIP_TRY(hipMalloc((void**)&s->d_stats, STAT_WORDS * sizeof(unsigned long long)));
@@ -2311,6 +2332,7 @@ static int scene_runtime_init(rt_scene* s, int device) {
   for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
   for (rt_scene::FrameSlot& f : s->slots) {
     HIP_TRY(hipMalloc((void**)&f.d_stats, STAT_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(f.d_stats, 0, STAT_WORDS * sizeof(unsigned long long)));  // k_stats_out leaves them zero after every frame
     HIP_TRY(hipHostMalloc((void**)&f.h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&f.begin));
     HIP_TRY(hipEventCreate(&f.end));
@@ -2825,7 +2847,7 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
   // ---- nothing may be in flight while the tables change
   int rc = collect_all(s);
   if (rc) return rc;
-  for (hipStream_t st : {s->stream, s->frame_stream, s->copy_stream}) HIP_TRY(hipStreamSynchronize(st));
+  for (hipStream_t st : {s->stream, s->frame_stream[0], s->frame_stream[1], s->frame_stream[2], s->copy_stream}) HIP_TRY(hipStreamSynchronize(st));
   if ((rc = reupload(s, RT_FIELD(tris), tris))) return rc;
   if ((rc = reupload(s, RT_FIELD(quads), quads))) return rc;
   if ((rc = reupload(s, RT_FIELD(gates), gates))) return rc;
@@ -2878,11 +2900,11 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
     }
     if (!tri_box.empty()) HIP_TRY(hipMemcpy(H.d_tri_box, tri_box.data(), tri_box.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!quad_box.empty()) HIP_TRY(hipMemcpy(H.d_quad_box, quad_box.data(), quad_box.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemsetAsync(H.d_arrived, 0, H.n_nodes * sizeof(uint32_t), s->stream));
+    HIP_TRY(hipMemsetAsync(H.d_arrived, 0, H.n_nodes * sizeof(uint32_t), main_stream(s)));
     RefitView v{const_cast<BvhNode*>(s->dev.nodes), H.d_tri_box, H.d_quad_box, s->dev.gates, H.d_parent, H.d_waits, H.d_arrived, H.n_nodes};
-    hipLaunchKernelGGL(k_refit, dim3((H.n_nodes + 255) / 256), dim3(256), 0, s->stream, v);
+    hipLaunchKernelGGL(k_refit, dim3((H.n_nodes + 255) / 256), dim3(256), 0, main_stream(s), v);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(main_stream(s)));
   }
   s->dev.root_alt = s->dev.root;  // with every gate tested, both kinds of ray walk the same references
   H.tris.swap(tris);
@@ -3119,6 +3141,18 @@ extern "C" void rt_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
+extern "C" int rt_host_register(void* p, uint64_t bytes) {
+  if (!p || bytes == 0) return fail(RT_ERR_INVALID, "rt_host_register: null or empty range");
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable));
+  return RT_OK;
+}
+
+extern "C" int rt_host_unregister(void* p) {
+  if (!p) return RT_OK;
+  HIP_TRY(hipHostUnregister(p));
+  return RT_OK;
+}
+
 extern "C" int rt_scene_build_info(const rt_scene* s, uint64_t* device_builds, double* device_build_seconds) {
   if (!s) return fail(RT_ERR_INVALID, "null scene");
   if (device_builds) *device_builds = s->device_builds;
@@ -3143,7 +3177,7 @@ int ensure_gen(rt_scene* s, int g, size_t cap) {
   if (cap == 0) cap = 64;
   if (b.capacity >= cap) return RT_OK;
   if (b.slab) {
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(main_stream(s)));
     HIP_TRY(hipFree(b.slab));
     b.slab = nullptr;
     b.capacity = 0;
@@ -3284,18 +3318,28 @@ int collect_all(rt_scene* s) {
   return RT_OK;
 }
 
+// Moves a frame's counters to page-locked host memory and leaves the device copy cleared for the slot's next frame.
+__global__ void k_stats_out(unsigned long long* __restrict__ dev, unsigned long long* __restrict__ host) {
+  const int i = threadIdx.x;
+  if (i < STAT_WORDS) {
+    host[i] = dev[i];
+    dev[i] = 0;
+  }
+}
+
 // One camera frame of a scene that spawns no rays: a single kernel, nothing to read back, so the
 // frame is only enqueued.
 int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
   rt_scene::FrameSlot& f = s->slots[s->next_slot];
   int rc = collect_frame(s, f);  // the slot's previous frame, FRAME_SLOTS frames ago
   if (rc) return rc;
-  // consecutive frames go to alternating streams: they do not depend on each other, and the tail of
+  // consecutive frames go to different streams: they do not depend on each other, and the tail of
   // one kernel (few waves left) overlaps the head of the next
-  hipStream_t stream = (s->next_slot & 1) ? s->frame_stream : s->stream;
+  const unsigned lane = s->frame_seq++ % (unsigned)s->n_frame_streams;
+  hipStream_t stream = lane ? s->frame_stream[lane - 1] : main_stream(s);
+  if (lane) s->frame_stream_used[lane - 1] = true;
   s->last_stream = stream;
   s->next_slot = (s->next_slot + 1) % rt_scene::FRAME_SLOTS;
-  HIP_TRY(hipMemsetAsync(f.d_stats, 0, STAT_WORDS * sizeof(unsigned long long), stream));
   GenLaunch a;
   a.cur = s->gens[0].view;
   a.next = s->gens[1].view;
@@ -3313,8 +3357,9 @@ int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
   launch_generation(s, 0, (in.flags & RT_FLAG_COUNTERS) != 0, a);
   HIP_TRY(hipEventRecord(f.end, stream));
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(f.h_stats, f.d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                         stream));
+  // one small kernel instead of a clearing fill before the frame and a copy after it: fewer packets per
+  // frame, and the copy engine is left to the frame downloads
+  hipLaunchKernelGGL(k_stats_out, dim3(1), dim3(256), 0, stream, f.d_stats, f.h_stats);
   HIP_TRY(hipEventRecord(f.done, stream));
   f.primary = primary;
   f.pending = true;
@@ -3345,13 +3390,13 @@ void fill_launch(rt_scene* s, const PipelineIn& in, const GenPlan& plan, int g, 
   a.tiles_x = in.tiles_x;
   a.img = in.img;
   a.stats = s->d_stats;
-  a.stream = s->stream;
+  a.stream = main_stream(s);
   a.queue_counts = g > 0 ? s->d_counts + (g - 1) * QUEUE_SEGMENTS : nullptr;
   a.segcap = plan.segcap[g];
 }
 
 void launch_resolve(rt_scene* s, const GenPlan& plan, int g) {
-  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(plan.threads[g])), dim3(BLOCK), 0, s->stream, s->gens[g].view,
+  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(plan.threads[g])), dim3(BLOCK), 0, main_stream(s), s->gens[g].view,
                      plan.threads[g], s->gens[g + 1].view,
                      g > 0 ? s->d_counts + (g - 1) * QUEUE_SEGMENTS : (const uint32_t*)nullptr, plan.segcap[g]);
 }
@@ -3360,7 +3405,7 @@ void launch_resolve(rt_scene* s, const GenPlan& plan, int g) {
 void launch_resolves(rt_scene* s, const PipelineIn& in, const GenPlan& plan, int last) {
   for (int g = last - 1; g >= (in.camera ? 1 : 0); g--) launch_resolve(s, plan, g);
   if (in.camera && last > 0)
-    hipLaunchKernelGGL(k_resolve_pixels, dim3(blocks_for(in.n0)), dim3(BLOCK), 0, s->stream, s->gens[0].view, in.n0,
+    hipLaunchKernelGGL(k_resolve_pixels, dim3(blocks_for(in.n0)), dim3(BLOCK), 0, main_stream(s), s->gens[0].view, in.n0,
                        s->gens[1].view, in.cam, in.tiles, in.tiles_x, in.img);
 }
 
@@ -3391,19 +3436,19 @@ int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_stats* st
   GenPlan plan;
   int last = 0, rc;
   if ((rc = plan_speculative(s, in, max_gen, plan, &last))) return rc;
-  HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+  HIP_TRY(hipEventRecord(s->ev[0], main_stream(s)));
   for (int g = 0; g <= last; g++) {
     GenLaunch a;
     fill_launch(s, in, plan, g, max_gen, a);
     launch_generation(s, (g == 0 && in.camera) ? 1 : 2, false, a);
   }
-  HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+  HIP_TRY(hipEventRecord(s->ev[1], main_stream(s)));
   launch_resolves(s, in, plan, last);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, main_stream(s)));
   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                         s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+                         main_stream(s)));
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
   *fits = true;
   int true_last = 0;
   for (int g = 1; g <= max_gen && *fits; g++) {  // counters [g - 1]: the rays queued for generation g
@@ -3444,8 +3489,8 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
   if (hinted && s->holdoff > 0) {
     s->holdoff--;
   } else if (hinted) {
-    HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), s->stream));
-    HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
+    HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
     bool fits = false;
     int rc = run_speculative(s, in, max_gen, stats, &fits);
     if (rc) return rc;
@@ -3460,8 +3505,8 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     static const bool debug = getenv("RT_AMD_DEBUG") != nullptr;
     if (debug) fprintf(stderr, "[rt_amd] speculative frame did not fit; exact for the next %u frames\n", s->holdoff);
   }
-  HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), s->stream));
-  if (max_gen > 0) HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), s->stream));
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
+  if (max_gen > 0) HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
   GenPlan plan;
   uint32_t fullest[MAX_GENERATIONS + 2] = {0};
   plan.threads[0] = in.n0;
@@ -3478,14 +3523,14 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     GenLaunch a;
     fill_launch(s, in, plan, g, max_gen, a);
     int mode = (g == 0 && in.camera) ? (direct ? 0 : 1) : 2;
-    HIP_TRY(hipEventRecord(s->ev[g * 2 + 0], s->stream));
+    HIP_TRY(hipEventRecord(s->ev[g * 2 + 0], main_stream(s)));
     launch_generation(s, mode, count, a);
-    HIP_TRY(hipEventRecord(s->ev[g * 2 + 1], s->stream));
+    HIP_TRY(hipEventRecord(s->ev[g * 2 + 1], main_stream(s)));
     if (g < max_gen) {
       uint32_t* h = s->h_counts + g * QUEUE_SEGMENTS;
       HIP_TRY(hipMemcpyAsync(h, s->d_counts + g * QUEUE_SEGMENTS, QUEUE_SEGMENTS * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                             s->stream));
-      HIP_TRY(hipStreamSynchronize(s->stream));
+                             main_stream(s)));
+      HIP_TRY(hipStreamSynchronize(main_stream(s)));
       uint64_t total = 0;
       for (int k = 0; k < QUEUE_SEGMENTS; k++) {
         total += std::min<uint32_t>(h[k], (uint32_t)next_segcap);
@@ -3497,7 +3542,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     {
       static unsigned long long before[STAMP_WORDS];
       if (g == 0) memset(before, 0, sizeof before);
-      HIP_TRY(hipStreamSynchronize(s->stream));  // the generation just launched (the copy below does not wait for this stream)
+      HIP_TRY(hipStreamSynchronize(main_stream(s)));  // the generation just launched (the copy below does not wait for this stream)
       HIP_TRY(hipMemcpy(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       const unsigned long long* t = s->h_stats + STAT_RAYS + 3 * STAT_SLOTS;
       double d[STAMP_WORDS], sum = 0;
@@ -3516,8 +3561,8 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
   launch_resolves(s, in, plan, last);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                         s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+                         main_stream(s)));
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
   if (max_gen > 0) {
     for (int g = 0; g <= MAX_GENERATIONS + 1; g++) s->hint[g] = fullest[g];
     s->hint_key[0] = in.n0;
@@ -3547,7 +3592,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
 int stage_reserve(rt_scene* s, size_t bytes) {
   if (s->stage_bytes >= bytes) return RT_OK;
   if (s->stage) {
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(main_stream(s)));
     HIP_TRY(hipFree(s->stage));
     s->stage = nullptr;
     s->stage_bytes = 0;
@@ -3574,14 +3619,14 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   if (memcmp(key, s->tiles_key, sizeof(key)) != 0) {
     int rcw = collect_all(s);  // frames in flight still read the current tile table
     if (rcw) return rcw;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(main_stream(s)));
     s->h_tiles.clear();
     for (uint32_t ty = 0; ty < tiles_y; ty++)
       for (uint32_t tx = 0; tx < tiles_x; tx++)
         if ((int)(((bands ? 0u : tx) + ty) % (uint32_t)n_parts) == part) s->h_tiles.push_back(ty * tiles_x + tx);
     if (s->tiles_capacity < s->h_tiles.size()) {
       if (s->d_tiles) {
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipStreamSynchronize(main_stream(s)));
         HIP_TRY(hipFree(s->d_tiles));
         s->d_tiles = nullptr;
       }
@@ -3662,10 +3707,17 @@ static int order_copy_stream(rt_scene* s, void* after_stream) {
     HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order, 0));
     return RT_OK;
   }
-  HIP_TRY(hipEventRecord(s->copy_order, s->stream));
-  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order, 0));
-  HIP_TRY(hipEventRecord(s->copy_order2, s->frame_stream));
-  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order2, 0));
+  if (s->stream_used) {  // nothing new on a stream since the last ordering otherwise
+    HIP_TRY(hipEventRecord(s->copy_order, s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order, 0));
+    s->stream_used = false;
+  }
+  for (int k = 0; k < rt_scene::FRAME_STREAMS - 1; k++) {
+    if (!s->frame_stream_used[k]) continue;
+    HIP_TRY(hipEventRecord(s->copy_order2[k], s->frame_stream[k]));
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->copy_order2[k], 0));
+    s->frame_stream_used[k] = false;
+  }
   return RT_OK;
 }
 
@@ -3719,8 +3771,8 @@ extern "C" int rt_render_host(rt_scene* s, const rt_camera* camera, int part, in
   int rc = stage_reserve(s, offl + bl + 256);
   if (rc) return rc;
   char* base = (char*)s->stage;
-  HIP_TRY(hipMemsetAsync(base, 0, offl + bl, s->stream));
-  if (hit_leaf) HIP_TRY(hipMemsetAsync(base + offl, 0xFF, bl, s->stream));
+  HIP_TRY(hipMemsetAsync(base, 0, offl + bl, main_stream(s)));
+  if (hit_leaf) HIP_TRY(hipMemsetAsync(base + offl, 0xFF, bl, main_stream(s)));
   rc = rt_render(s, camera, part, n_parts, flags & ~(uint32_t)(RT_FLAG_ASYNC | RT_FLAG_COMPACT), rgb8 ? (uint8_t*)base : nullptr,
                  rgb64 ? (double*)(base + off64) : nullptr, hit_leaf ? (int32_t*)(base + offl) : nullptr, stats);
   if (rc) return rc;
@@ -3729,15 +3781,15 @@ extern "C" int rt_render_host(rt_scene* s, const rt_camera* camera, int part, in
     const size_t rows_total = camera->vsize, w = camera->hsize;
     for (size_t y0 = (size_t)part * TILE; y0 < rows_total; y0 += (size_t)n_parts * TILE) {
       const size_t rows = std::min<size_t>(TILE, rows_total - y0), px = y0 * w, n = rows * w;
-      if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8 + px * 3, base + px * 3, n * 3, hipMemcpyDeviceToHost, s->stream));
+      if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8 + px * 3, base + px * 3, n * 3, hipMemcpyDeviceToHost, main_stream(s)));
       if (rgb64)
         HIP_TRY(hipMemcpyAsync(rgb64 + px * 3, base + off64 + px * 3 * sizeof(double), n * 3 * sizeof(double),
-                               hipMemcpyDeviceToHost, s->stream));
+                               hipMemcpyDeviceToHost, main_stream(s)));
       if (hit_leaf)
         HIP_TRY(hipMemcpyAsync(hit_leaf + px, base + offl + px * sizeof(int32_t), n * sizeof(int32_t),
-                               hipMemcpyDeviceToHost, s->stream));
+                               hipMemcpyDeviceToHost, main_stream(s)));
     }
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(main_stream(s)));
     return RT_OK;
   }
   if (rgb8) HIP_TRY(hipMemcpy(rgb8, base, b8, hipMemcpyDeviceToHost));
@@ -3757,12 +3809,12 @@ extern "C" int rt_ray_for_pixel(rt_scene* s, const rt_camera* camera, uint64_t n
   if (rc) return rc;
   double* d_rays = (double*)s->stage;
   uint32_t* d_xy = (uint32_t*)(d_rays + n * 6);
-  HIP_TRY(hipMemcpyAsync(d_xy, xy, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(k_pixel_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, camera_dev(camera), (uint32_t)n,
+  HIP_TRY(hipMemcpyAsync(d_xy, xy, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, main_stream(s)));
+  hipLaunchKernelGGL(k_pixel_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, main_stream(s), camera_dev(camera), (uint32_t)n,
                      d_xy, d_rays);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(rays6, d_rays, n * 6 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpyAsync(rays6, d_rays, n * 6 * sizeof(double), hipMemcpyDeviceToHost, main_stream(s)));
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
   return RT_OK;
 }
 
@@ -3772,8 +3824,8 @@ static int load_user_rays(rt_scene* s, uint64_t n, const double* rays6) {
   if (rc) return rc;
   rc = stage_reserve(s, n * 6 * sizeof(double) + n * 16);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(s->stage, rays6, n * 6 * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(k_load_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, (uint32_t)n,
+  HIP_TRY(hipMemcpyAsync(s->stage, rays6, n * 6 * sizeof(double), hipMemcpyHostToDevice, main_stream(s)));
+  hipLaunchKernelGGL(k_load_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, main_stream(s), s->gens[0].view, (uint32_t)n,
                      (const double*)s->stage);
   return RT_OK;
 }
@@ -3798,12 +3850,12 @@ extern "C" int rt_color_at(rt_scene* s, uint64_t n, const double* rays6, int rem
   // the staged rays are consumed: reuse the buffer for the results
   double* d_rgb = (double*)s->stage;
   int32_t* d_leaf = (int32_t*)(d_rgb + n * 3);
-  hipLaunchKernelGGL(k_output_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s->stream, s->gens[0].view, (uint32_t)n,
+  hipLaunchKernelGGL(k_output_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, main_stream(s), s->gens[0].view, (uint32_t)n,
                      d_rgb, d_leaf, (double*)nullptr);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(rgb, d_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  if (leaf) HIP_TRY(hipMemcpyAsync(leaf, d_leaf, n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpyAsync(rgb, d_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost, main_stream(s)));
+  if (leaf) HIP_TRY(hipMemcpyAsync(leaf, d_leaf, n * sizeof(int32_t), hipMemcpyDeviceToHost, main_stream(s)));
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
   if (stats) {
     stats->primary = n;
     stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
@@ -3819,19 +3871,19 @@ extern "C" int rt_intersect_hit(rt_scene* s, uint64_t n, const double* rays6, do
   if (rc) return rc;
   dim3 grid(blocks_for(n)), block(BLOCK);
   if (s->has_csg)
-    hipLaunchKernelGGL((k_intersect<64, true>), grid, block, csg_lds_bytes(s), s->stream, s->dev, s->gens[0].view, (uint32_t)n);
+    hipLaunchKernelGGL((k_intersect<64, true>), grid, block, csg_lds_bytes(s), main_stream(s), s->dev, s->gens[0].view, (uint32_t)n);
   else if (pick_stack(s->stack_need) == STACK_SMALL)
-    hipLaunchKernelGGL((k_intersect<STACK_SMALL, false>), grid, block, 0, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
+    hipLaunchKernelGGL((k_intersect<STACK_SMALL, false>), grid, block, 0, main_stream(s), s->dev, s->gens[0].view, (uint32_t)n);
   else
-    hipLaunchKernelGGL((k_intersect<64, false>), grid, block, 0, s->stream, s->dev, s->gens[0].view, (uint32_t)n);
+    hipLaunchKernelGGL((k_intersect<64, false>), grid, block, 0, main_stream(s), s->dev, s->gens[0].view, (uint32_t)n);
   double* d_t = (double*)s->stage;
   int32_t* d_leaf = (int32_t*)(d_t + n);
-  hipLaunchKernelGGL(k_output_rays, grid, block, 0, s->stream, s->gens[0].view, (uint32_t)n, (double*)nullptr, d_leaf,
+  hipLaunchKernelGGL(k_output_rays, grid, block, 0, main_stream(s), s->gens[0].view, (uint32_t)n, (double*)nullptr, d_leaf,
                      d_t);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipMemcpyAsync(leaf, d_leaf, n * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpyAsync(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost, main_stream(s)));
+  HIP_TRY(hipMemcpyAsync(leaf, d_leaf, n * sizeof(int32_t), hipMemcpyDeviceToHost, main_stream(s)));
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
   return RT_OK;
 }
 
@@ -3844,16 +3896,16 @@ extern "C" int rt_is_shadowed(rt_scene* s, uint64_t n, const double* points3, ui
   if (rc) return rc;
   double* d_pts = (double*)s->stage;
   uint8_t* d_out = (uint8_t*)(d_pts + n * 3);
-  HIP_TRY(hipMemcpyAsync(d_pts, points3, n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(d_pts, points3, n * 3 * sizeof(double), hipMemcpyHostToDevice, main_stream(s)));
   dim3 grid(blocks_for(n)), block(BLOCK);
   if (s->has_csg)
-    hipLaunchKernelGGL((k_points_shadowed<64, true>), grid, block, csg_lds_bytes(s), s->stream, s->dev, (uint32_t)n, d_pts, d_out);
+    hipLaunchKernelGGL((k_points_shadowed<64, true>), grid, block, csg_lds_bytes(s), main_stream(s), s->dev, (uint32_t)n, d_pts, d_out);
   else if (pick_stack(s->stack_need) == STACK_SMALL)
-    hipLaunchKernelGGL((k_points_shadowed<STACK_SMALL, false>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
+    hipLaunchKernelGGL((k_points_shadowed<STACK_SMALL, false>), grid, block, 0, main_stream(s), s->dev, (uint32_t)n, d_pts, d_out);
   else
-    hipLaunchKernelGGL((k_points_shadowed<64, false>), grid, block, 0, s->stream, s->dev, (uint32_t)n, d_pts, d_out);
+    hipLaunchKernelGGL((k_points_shadowed<64, false>), grid, block, 0, main_stream(s), s->dev, (uint32_t)n, d_pts, d_out);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(shadowed, d_out, n, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpyAsync(shadowed, d_out, n, hipMemcpyDeviceToHost, main_stream(s)));
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
   return RT_OK;
 }

@@ -1158,10 +1158,14 @@ void check_rt(int rc) {
 
 }  // namespace
 
-FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth)
+FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth, const Share& share)
     : devices_(devices), depth_(depth) {
   if (devices.empty()) throw Panic("assertion failed: size > 0");  // src/parallel.rs:94
   if (depth < 1 || depth > 8) throw std::invalid_argument("FrameLoop: depth must lie in 1..8");
+  first_part_ = share.first_part;
+  total_parts_ = share.total_parts ? share.total_parts : devices.size();
+  if (first_part_ + devices.size() > total_parts_) throw std::invalid_argument("FrameLoop: more parts than the frame has");
+  own_ring_ = share.ring == nullptr;
   cam_ = camera.describe();
   frame_bytes_ = (size_t)cam_.hsize * cam_.vsize * 3;
   if (frame_bytes_ == 0) throw std::invalid_argument("FrameLoop: empty canvas");
@@ -1173,7 +1177,7 @@ FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector
     check_rt(rt_scene_footprint(scenes_[0], nullptr, &build_seconds_));
     for (size_t k = 1; k < devices.size(); k++) check_rt(rt_scene_clone(scenes_[0], devices[k], &scenes_[k]));
     for (int k = 0; k < depth; k++) {
-      uint8_t* p = (uint8_t*)rt_host_alloc(frame_bytes_);
+      uint8_t* p = own_ring_ ? (uint8_t*)rt_host_alloc(frame_bytes_) : share.ring + (size_t)k * frame_bytes_;
       if (!p) throw std::runtime_error("FrameLoop: no page-locked host memory for the frame ring");
       host_.push_back(p);
     }
@@ -1196,7 +1200,8 @@ void FrameLoop::release() {
   dev_frames_.clear();
   for (rt_scene* s : scenes_) rt_scene_destroy(s);
   scenes_.clear();
-  for (uint8_t* p : host_) rt_host_free(p);
+  if (own_ring_)
+    for (uint8_t* p : host_) rt_host_free(p);
   host_.clear();
 }
 
@@ -1209,15 +1214,16 @@ uint64_t FrameLoop::scene_bytes() const {
 }
 
 FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
-  const size_t n = scenes_.size();
+  const size_t workers = scenes_.size(), n = total_parts_;  // n: parts of the frame, of which this loop renders `workers`
   Result result;
-  result.part.assign(n, rt_stats{});
-  std::vector<std::string> errors(n);
-  Rendezvous meet(n);
+  result.part.assign(workers, rt_stats{});
+  std::vector<std::string> errors(workers);
+  Rendezvous meet(workers);
   std::chrono::steady_clock::time_point t0, t1;
   const size_t w = cam_.hsize, rows_total = cam_.vsize, band_bytes = (size_t)32 * w * 3;
   auto worker = [&](size_t k) {
     rt_scene* sc = scenes_[k];
+    const size_t part = first_part_ + k;
     bool ok = true;
     auto frame = [&](size_t f) {
       if (!ok) return;
@@ -1225,13 +1231,13 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
       uint8_t* dev = dev_frames_[k][(size_t)slot];
       // the copy that last read this device frame (depth frames ago) must be through before it is rendered over
       if (to_host && rt_copy_wait(sc, (uint32_t)slot) != RT_OK) ok = false;
-      if (ok && rt_render(sc, &cam_, (int)k, (int)n, RT_FLAG_ASYNC | RT_FLAG_BANDS, dev, nullptr, nullptr, nullptr) != RT_OK) ok = false;
+      if (ok && rt_render(sc, &cam_, (int)part, (int)n, RT_FLAG_ASYNC | RT_FLAG_BANDS, dev, nullptr, nullptr, nullptr) != RT_OK) ok = false;
       if (ok && to_host && n == 1) {  // the whole frame is this part's: one contiguous copy
         if (rt_download(sc, dev, host_[(size_t)slot], frame_bytes_, nullptr) != RT_OK) ok = false;
         if (ok && rt_copy_fence(sc, (uint32_t)slot) != RT_OK) ok = false;
       } else if (ok && to_host) {
         // this part's bands: whole bands with one strided copy, a last partial band with a plain one
-        const size_t first = k * 32, n_bands_mine = first < rows_total ? (rows_total - first + n * 32 - 1) / (n * 32) : 0;
+        const size_t first = part * 32, n_bands_mine = first < rows_total ? (rows_total - first + n * 32 - 1) / (n * 32) : 0;
         size_t whole = n_bands_mine;
         if (n_bands_mine && first + (n_bands_mine - 1) * n * 32 + 32 > rows_total) whole--;
         uint8_t* host = host_[(size_t)slot];
@@ -1262,7 +1268,7 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     if (k == 0) t1 = std::chrono::steady_clock::now();
   };
   std::vector<std::thread> threads;
-  for (size_t k = 1; k < n; k++) threads.emplace_back(worker, k);
+  for (size_t k = 1; k < workers; k++) threads.emplace_back(worker, k);
   worker(0);
   for (auto& t : threads) t.join();
   for (const std::string& e : errors)
@@ -1276,7 +1282,7 @@ std::vector<rt_stats> FrameLoop::blocking_frames(size_t frames, bool counters) {
   for (size_t f = 0; f < frames; f++)
     for (size_t k = 0; k < scenes_.size(); k++) {
       rt_stats st{};
-      check_rt(rt_render(scenes_[k], &cam_, (int)k, (int)scenes_.size(), (counters ? RT_FLAG_COUNTERS : 0u) | RT_FLAG_BANDS,
+      check_rt(rt_render(scenes_[k], &cam_, (int)(first_part_ + k), (int)total_parts_, (counters ? RT_FLAG_COUNTERS : 0u) | RT_FLAG_BANDS,
                          dev_frames_[k][0], nullptr, nullptr, &st));
       rt_stats& o = out[k];
       o.primary += st.primary; o.shadow += st.shadow; o.reflect += st.reflect; o.refract += st.refract;

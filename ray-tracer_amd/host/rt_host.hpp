@@ -144,9 +144,19 @@ class FrameLoop {
     double seconds = 0;          // wall time of the timed frames: start barrier -> all workers drained
     std::vector<rt_stats> part;  // per part: sums over its timed frames (rays by kind, kernel time, launches)
   };
+  // A loop that renders only some parts of the frame, for one process per GPU: this process's devices
+  // take parts first_part, first_part + 1, ... of total_parts, and the frames are assembled in `ring`
+  // (depth frames back to back; page-locked or registered with rt_host_register by the caller, who
+  // keeps it alive; typically a shared-memory mapping that every process of the job opens).
+  struct Share {
+    size_t first_part = 0, total_parts = 0;  // total_parts 0: the devices given are all the parts
+    uint8_t* ring = nullptr;                 // nullptr: the loop allocates its own ring
+  };
   // devices[k]: GPU of part k (the same GPU may serve several parts).  depth: frames in flight per worker
   // and host frames in the ring (1..8).
-  FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth);
+  FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth, const Share& share);
+  FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth)
+      : FrameLoop(world, camera, devices, depth, Share()) {}
   ~FrameLoop();
   FrameLoop(const FrameLoop&) = delete;
   FrameLoop& operator=(const FrameLoop&) = delete;
@@ -170,6 +180,8 @@ class FrameLoop {
   std::vector<std::vector<uint8_t*>> dev_frames_;  // [part][slot], on the part's GPU
   std::vector<uint8_t*> host_;                     // [slot], page-locked, shared by all parts
   size_t frame_bytes_ = 0;
+  size_t first_part_ = 0, total_parts_ = 0;
+  bool own_ring_ = true;
   int depth_ = 0;
   double build_seconds_ = 0;
   void release();

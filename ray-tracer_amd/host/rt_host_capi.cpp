@@ -205,6 +205,24 @@ int rth_frame_loop_new(rth_scene* h, uint64_t parts, const int32_t* devices, int
   });
 }
 
+// One process per GPU: this process renders parts first_part .. first_part + parts - 1 of total_parts into
+// `ring` (depth frames back to back, registered by the caller with rt_host_register, shared by the processes).
+int rth_frame_loop_new_shared(rth_scene* h, uint64_t parts, const int32_t* devices, int32_t depth, uint64_t first_part,
+                              uint64_t total_parts, uint8_t* ring, rth_frame_loop** out) {
+  *out = nullptr;
+  return guarded([&]() -> int {
+    std::vector<int> dev(devices, devices + parts);
+    FrameLoop::Share share;
+    share.first_part = first_part;
+    share.total_parts = total_parts;
+    share.ring = ring;
+    std::unique_ptr<rth_frame_loop> l(new rth_frame_loop());
+    l->loop.reset(new FrameLoop(h->scene.world, h->scene.camera, dev, depth, share));
+    *out = l.release();
+    return RT_OK;
+  });
+}
+
 void rth_frame_loop_free(rth_frame_loop* l) { delete l; }
 
 // stats: one rt_stats per part.  *seconds: wall time of the timed frames.

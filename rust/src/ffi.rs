@@ -128,6 +128,8 @@ extern "C" {
     pub fn rt_copy_wait(scene: *mut rt_scene, slot: u32) -> c_int;
     pub fn rt_host_alloc(bytes: u64) -> *mut c_void;
     pub fn rt_host_free(p: *mut c_void);
+    pub fn rt_host_register(p: *mut c_void, bytes: u64) -> c_int;
+    pub fn rt_host_unregister(p: *mut c_void) -> c_int;
     pub fn rt_device_alloc(device: c_int, bytes: u64, out: *mut *mut c_void) -> c_int;
     pub fn rt_device_free(device: c_int, p: *mut c_void);
     pub fn rt_render_host(scene: *mut rt_scene, camera: *const rt_camera, part: c_int, n_parts: c_int, flags: u32,

@@ -74,3 +74,27 @@ def test_bench_runs_bare_with_two_gpus_requested(root):
     for line in (one, two):
         assert line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
         assert line["roofline"]["frac"] > 0 and line["roofline"]["launches_per_frame"] == line["n_gpus"]
+
+
+def test_bench_under_the_launcher_assembles_the_same_frame(root):
+    """bench.py as the round-end driver starts it for N > 1 (torch.distributed.run, one rank per GPU), here with
+    both ranks on the one GPU and gloo for the barriers: the frame the two ranks assemble in the shared ring
+    equals the frame of the one-GPU run, and the ray count is the same."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    one = run_bench(root, "--gpus", "1", "--steps", "3", "--warmup", "1")
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-hbm-leg"],
+                         capture_output=True, text=True, timeout=400, env=env)
+    assert out.returncode == 0, "\n".join(l for l in out.stderr.splitlines() if l.startswith("[rank"))[-3000:]
+    two = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["steps"] == 3 and two["value"] > 0
+    assert two["frame_sha256"] == one["frame_sha256"]
+    assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+    assert "no collective" in two["config"]["parallelism"]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt_amd_bench_")]

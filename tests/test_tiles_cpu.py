@@ -1,6 +1,7 @@
 """The multi-GPU partition and framebuffer gather, exercised on CPU with two gloo ranks."""
 import os
 import socket
+import sys
 
 import numpy as np
 import torch
@@ -82,6 +83,66 @@ def test_two_rank_gather_rebuilds_the_frame():
     out = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, 150, 100, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) is True
+
+
+def _ring_worker(rank, world, port, w, h, out):
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        depth = 3
+        name = ["rt_amd_test_%d" % os.getpid()] if rank == 0 else [None]
+        dist.broadcast_object_list(name, src=0)
+        ring = pkg.bindings.SharedFrameRing(name[0], w, h, depth, create=True, register=False) if rank == 0 else None
+        dist.barrier()
+        ok = True
+        if rank != 0:
+            try:
+                pkg.bindings.SharedFrameRing(name[0], w, h + 1, depth, create=False, register=False)
+                ok = False  # a ring of another size must be refused
+            except ValueError:
+                pass
+            ring = pkg.bindings.SharedFrameRing(name[0], w, h, depth, create=False, register=False)
+        ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        truth = np.stack([xs % 251, ys % 241, (xs * 7 + ys * 13) % 239], axis=-1).astype(np.uint8)
+        for slot in range(depth):  # what this rank's GPU copies: its own bands of 32 rows, nothing else
+            for y0, y1 in pkg.tiles.part_bands(h, rank, world):
+                ring.frame(slot)[y0:y1] = truth[y0:y1] + slot
+        dist.barrier()
+        if rank == 0:
+            for slot in range(depth):
+                ok = ok and bool(np.array_equal(ring.frame(slot), truth + slot))
+        flag = [ok]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, flag)
+        dist.barrier()
+        path = ring.path
+        ring.close()
+        dist.barrier()
+        if rank == 0:
+            out.put(all(g[0] for g in gathered) and not os.path.exists(path))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_assemble_frames_in_a_shared_ring():
+    """The launcher path of bench.py without its GPU work: two processes map one shared-memory ring, each
+    writes only its own bands, and rank 0 reads whole frames; the creator removes the file."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, 70, 100, out)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
