@@ -148,6 +148,9 @@ struct Counters {
   unsigned long long* sink;  // four sums: unbounded + setup, node loop, triangle runs, quadric runs + gates
   unsigned long long tt;
 #endif
+#if defined(RT_WAVE_CLOCK_IMAGE) && RT_WAVE_CLOCK_IMAGE == 2
+  unsigned wi[4];  // this lane's share of the wave-level loop iterations (it counts those it leads)
+#endif
 };
 #ifdef RT_STAMPS
 // one count per wave and loop iteration (by the first active lane): lane events / (64 x these) = lane utilisation
@@ -156,6 +159,10 @@ struct Counters {
 #define RT_TSTAMP(c, k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
     if ((c).sink && (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd((c).sink + (k), now_ - (c).tt); \
     (c).tt = now_; } while (0)
+#elif defined(RT_WAVE_CLOCK_IMAGE) && RT_WAVE_CLOCK_IMAGE == 2
+#define RT_TBEGIN(c) do { } while (0)
+#define RT_TSTAMP(c, k) do { } while (0)
+#define RT_WAVE_ITER(c, k) do { if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) (c).wi[k]++; } while (0)
 #else
 #define RT_TBEGIN(c) do { } while (0)
 #define RT_TSTAMP(c, k) do { } while (0)
@@ -1257,6 +1264,9 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
 #ifdef RT_STAMPS
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef RT_WAVE_CLOCK_IMAGE  // diagnostic build: the frame shows how long each wave ran instead of the colours
+  const unsigned long long wave_begin_ = __builtin_amdgcn_s_memtime();
+#endif
   // i: the thread's ray; rec: where the ray's record lives.  Camera rays and rays handed in by the
   // caller are dense (rec == i, n of them); spawned rays are found through the segment counters the
   // generation before left in queue_counts, and n only bounds the grid.
@@ -1471,6 +1481,24 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     out_b = SQ.found ? ab : lb;
   }
   RT_STAMP(3);  // shadow traversal
+#ifdef RT_WAVE_CLOCK_IMAGE
+  {
+#if RT_WAVE_CLOCK_IMAGE == 2  // wave-level iterations instead: node visits in the low 12 bits, triangle tests above
+    unsigned nodes_ = ct.wi[0] + cs.wi[0], tris_ = ct.wi[1] + cs.wi[1];
+    for (int off = 32; off > 0; off >>= 1) {
+      nodes_ += __shfl_xor(nodes_, off);
+      tris_ += __shfl_xor(tris_, off);
+    }
+    const unsigned long long ticks = (nodes_ < 4095u ? nodes_ : 4095u) | ((tris_ < 4095u ? tris_ : 4095u) << 12);
+#else
+    const unsigned long long ticks = __builtin_amdgcn_s_memtime() - wave_begin_;  // 24 bits into the three bytes
+#endif
+    const unsigned b0 = ticks & 255u, b1 = (ticks >> 8) & 255u, b2 = (ticks >> 16) & 255u;
+    out_r = b0 ? (b0 - 0.5) / 255.0 : 0.0;
+    out_g = b1 ? (b1 - 0.5) / 255.0 : 0.0;
+    out_b = b2 ? (b2 - 0.5) / 255.0 : 0.0;
+  }
+#endif
   if (MODE != 2) write_pixel(img, cam.hsize, px, py, i, active, out_r, out_g, out_b, leaf);
   if (MODE != 0 && keep_record) {
     g.cr[rec] = out_r; g.cg[rec] = out_g; g.cb[rec] = out_b;
@@ -1793,12 +1821,15 @@ struct rt_scene {
   // frames enqueued under RT_FLAG_ASYNC and not collected yet: a small ring, each slot with its own
   // statistics block so consecutive frames do not share counters
   struct FrameSlot {
-    unsigned long long* d_stats = nullptr;
-    unsigned long long* h_stats = nullptr;
-    hipEvent_t begin = nullptr, end = nullptr, done = nullptr;
+    hipEvent_t begin = nullptr, end = nullptr;
     bool pending = false;
     uint64_t primary = 0;
   };
+  // Counters of the asynchronous frames: every such frame adds to the same device words (nothing per frame
+  // crosses PCIe or needs a launch of its own); they are read and cleared when the frames are collected.
+  unsigned long long* d_async_stats = nullptr;
+  unsigned long long* h_async_stats = nullptr;
+  bool async_counters_dirty = false;
   static constexpr int FRAME_SLOTS = 8;
   FrameSlot slots[FRAME_SLOTS];
   int next_slot = 0;
@@ -2289,12 +2320,11 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (p) (void)hipFree(p);
   for (hipEvent_t e : s->ev)
     if (e) (void)hipEventDestroy(e);
-  for (rt_scene::FrameSlot& f : s->slots) {
-    if (f.d_stats) (void)hipFree(f.d_stats);
-    if (f.h_stats) (void)hipHostFree(f.h_stats);
-    for (hipEvent_t e : {f.begin, f.end, f.done})
+  if (s->d_async_stats) (void)hipFree(s->d_async_stats);
+  if (s->h_async_stats) (void)hipHostFree(s->h_async_stats);
+  for (rt_scene::FrameSlot& f : s->slots)
+    for (hipEvent_t e : {f.begin, f.end})
       if (e) (void)hipEventDestroy(e);
-  }
   if (s->copy_stream) {
     (void)hipStreamSynchronize(s->copy_stream);
     (void)hipStreamDestroy(s->copy_stream);
@@ -2330,13 +2360,12 @@ static int scene_runtime_init(rt_scene* s, int device) {
   HIP_TRY(hipHostMalloc((void**)&s->h_counts, COUNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&s->h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
   for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipMalloc((void**)&s->d_async_stats, STAT_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->d_async_stats, 0, STAT_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_async_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
   for (rt_scene::FrameSlot& f : s->slots) {
-    HIP_TRY(hipMalloc((void**)&f.d_stats, STAT_WORDS * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(f.d_stats, 0, STAT_WORDS * sizeof(unsigned long long)));  // k_stats_out leaves them zero after every frame
-    HIP_TRY(hipHostMalloc((void**)&f.h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&f.begin));
     HIP_TRY(hipEventCreate(&f.end));
-    HIP_TRY(hipEventCreate(&f.done));
   }
   return RT_OK;
 }
@@ -3275,14 +3304,34 @@ void decode_stats(const unsigned long long* h, rt_stats* stats) {
   stats->shadow_gate_tests = h[7];
 }
 
-// Waits for one asynchronous frame and adds its statistics to the scene's running total.
+// Waits for one asynchronous frame and adds its kernel time to the scene's running total.
 int collect_frame(rt_scene* s, rt_scene::FrameSlot& f) {
   if (!f.pending) return RT_OK;
-  HIP_TRY(hipEventSynchronize(f.done));
+  HIP_TRY(hipEventSynchronize(f.end));
   f.pending = false;
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, f.begin, f.end));
+  rt_stats& t = s->async_total;
+  t.primary += f.primary;
+  t.kernel_ms += ms;
+  t.kernel_launches += 1;
+  t.generations += 1;
+  return RT_OK;
+}
+
+// Waits for every asynchronous frame, then reads and clears the counters they added to.
+int collect_all(rt_scene* s) {
+  for (int k = 0; k < rt_scene::FRAME_SLOTS; k++) {
+    int rc = collect_frame(s, s->slots[(s->next_slot + k) % rt_scene::FRAME_SLOTS]);
+    if (rc) return rc;
+  }
+  if (!s->async_counters_dirty) return RT_OK;
+  HIP_TRY(hipMemcpy(s->h_async_stats, s->d_async_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(s->d_async_stats, 0, STAT_WORDS * sizeof(unsigned long long)));
+  s->async_counters_dirty = false;
 #ifdef RT_STAMPS
   {
-    const unsigned long long* t = f.h_stats + STAT_RAYS + 3 * STAT_SLOTS;
+    const unsigned long long* t = s->h_async_stats + STAT_RAYS + 3 * STAT_SLOTS;
     double sum = 0;
     for (int k = 0; k < 5; k++) sum += (double)t[k];
     fprintf(stderr, "[rt_amd] wave clock shares: raygen %.3f closest %.3f shade %.3f shadow %.3f output %.3f (total %.3g ticks)\n",
@@ -3294,37 +3343,14 @@ int collect_frame(rt_scene* s, rt_scene::FrameSlot& f) {
   }
 #endif
   rt_stats one{};
-  decode_stats(f.h_stats, &one);
-  float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, f.begin, f.end));
+  decode_stats(s->h_async_stats, &one);
   rt_stats& t = s->async_total;
-  t.primary += f.primary;
   t.shadow += one.shadow; t.reflect += one.reflect; t.refract += one.refract;
-  t.kernel_ms += ms;
-  t.kernel_launches += 1;
-  t.generations += 1;
   t.node_visits += one.node_visits; t.tri_tests += one.tri_tests;
   t.quadric_tests += one.quadric_tests; t.gate_tests += one.gate_tests;
   t.shadow_node_visits += one.shadow_node_visits; t.shadow_tri_tests += one.shadow_tri_tests;
   t.shadow_quadric_tests += one.shadow_quadric_tests; t.shadow_gate_tests += one.shadow_gate_tests;
   return RT_OK;
-}
-
-int collect_all(rt_scene* s) {
-  for (int k = 0; k < rt_scene::FRAME_SLOTS; k++) {
-    int rc = collect_frame(s, s->slots[(s->next_slot + k) % rt_scene::FRAME_SLOTS]);
-    if (rc) return rc;
-  }
-  return RT_OK;
-}
-
-// Moves a frame's counters to page-locked host memory and leaves the device copy cleared for the slot's next frame.
-__global__ void k_stats_out(unsigned long long* __restrict__ dev, unsigned long long* __restrict__ host) {
-  const int i = threadIdx.x;
-  if (i < STAT_WORDS) {
-    host[i] = dev[i];
-    dev[i] = 0;
-  }
 }
 
 // One camera frame of a scene that spawns no rays: a single kernel, nothing to read back, so the
@@ -3335,7 +3361,9 @@ int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
   if (rc) return rc;
   // consecutive frames go to different streams: they do not depend on each other, and the tail of
   // one kernel (few waves left) overlaps the head of the next
-  const unsigned lane = s->frame_seq++ % (unsigned)s->n_frame_streams;
+  // a whole frame fills the GPU from two streams (a third only stretches every launch); a part of a frame does not
+  const unsigned lanes = in.tiles ? (unsigned)s->n_frame_streams : std::min(2u, (unsigned)s->n_frame_streams);
+  const unsigned lane = s->frame_seq++ % lanes;
   hipStream_t stream = lane ? s->frame_stream[lane - 1] : main_stream(s);
   if (lane) s->frame_stream_used[lane - 1] = true;
   s->last_stream = stream;
@@ -3351,16 +3379,13 @@ int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
   a.tiles = in.tiles;
   a.tiles_x = in.tiles_x;
   a.img = in.img;
-  a.stats = f.d_stats;
+  a.stats = s->d_async_stats;
+  s->async_counters_dirty = true;
   a.stream = stream;
   HIP_TRY(hipEventRecord(f.begin, stream));
   launch_generation(s, 0, (in.flags & RT_FLAG_COUNTERS) != 0, a);
   HIP_TRY(hipEventRecord(f.end, stream));
   HIP_TRY(hipGetLastError());
-  // one small kernel instead of a clearing fill before the frame and a copy after it: fewer packets per
-  // frame, and the copy engine is left to the frame downloads
-  hipLaunchKernelGGL(k_stats_out, dim3(1), dim3(256), 0, stream, f.d_stats, f.h_stats);
-  HIP_TRY(hipEventRecord(f.done, stream));
   f.primary = primary;
   f.pending = true;
   return RT_OK;

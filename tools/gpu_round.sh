@@ -35,3 +35,16 @@ for t in trace_hbm trace_host; do f=$(find $O/$t -name "*kernel_stats.csv" -prin
 # keep the merged output small: the raw traces and counter CSVs stay on the box
 rm -rf $O/trace_hbm $O/trace_host $O/pmc $O/pmc_traffic
 ls $O
+# what one GPU of an N-GPU run does (part 0..N-1 of N alone on this GPU), copy rates, host registration
+timeout -k 10 200 python3 tools/part_period.py > $O/part_period.txt 2>&1 || { echo "part_period failed"; exit 1; }
+if [ -x ray-tracer_amd/lib/d2h_probe ]; then timeout -k 10 100 ray-tracer_amd/lib/d2h_probe > $O/d2h_probe.txt 2>&1 || exit 1; fi
+if [ -x ray-tracer_amd/lib/register_probe ]; then timeout -k 10 100 ray-tracer_amd/lib/register_probe > $O/register_probe.txt 2>&1 || exit 1; fi
+# the launcher path, two ranks on this one GPU (gloo for the barriers): a rehearsal, no scaling figure
+RT_BENCH_BACKEND=gloo timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_gloo_rehearsal.json 2> $O/bench_2ranks.err || { echo "2-rank rehearsal failed"; exit 1; }
+# per-wave run times and loop iterations (diagnostic builds, when present)
+if [ -f ray-tracer_amd/lib/librt_host_wclk.so ] && [ -f ray-tracer_amd/lib/librt_host_wit.so ]; then
+  RT_AMD_LIB=librt_amd_wclk.so RT_HOST_LIB=librt_host_wclk.so timeout -k 10 200 python3 tools/wave_clock.py > $O/wave_clock.jsonl 2> /dev/null || exit 1
+  RT_AMD_LIB=librt_amd_wit.so RT_HOST_LIB=librt_host_wit.so timeout -k 10 200 python3 tools/wave_clock.py > /dev/null 2>&1 || exit 1
+  python3 tools/wave_iters.py gpurun_out/wave_wclk_teapot.npy gpurun_out/wave_wit_teapot.npy > $O/wave_iterations.txt || exit 1
+fi
+ls $O

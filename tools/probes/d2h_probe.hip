@@ -1,5 +1,5 @@
 // Device-to-host copy rate for one 1080p RGB8 frame (6.2 MB) into page-locked memory:
-// Build: hipcc -O2 --offload-arch=gfx950 tools/probes/d2h_probe.hip -o ray-tracer_amd/lib/d2h_probe (run on the GPU box).
+// Build: make -C ray-tracer_amd probes (lib/d2h_probe; run it on the GPU box).
 // one copy per frame on one stream, or the frame split over several streams.
 #include <hip/hip_runtime.h>
 #include <chrono>

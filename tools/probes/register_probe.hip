@@ -1,5 +1,5 @@
 // Which kinds of host memory hipHostRegister accepts on this machine: heap, anonymous shared, a /dev/shm file.
-// Build: hipcc -O2 --offload-arch=gfx950 tools/probes/register_probe.hip -o ray-tracer_amd/lib/register_probe (run on the GPU box).
+// Build: make -C ray-tracer_amd probes (lib/register_probe; run it on the GPU box).
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/mman.h>
