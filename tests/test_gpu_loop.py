@@ -33,6 +33,32 @@ def test_parts_fill_one_host_frame(pkg, root, name, size):
         loop.close()
 
 
+def test_loops_that_render_some_parts_share_a_ring(pkg, root):
+    """One loop per part, as one process per GPU runs them: part k of 3 into a ring the caller owns; after all
+    three have run, every ring slot holds the whole frame."""
+    path = os.path.join(root, "scenes", "teapot.json")
+    whole = pkg.Scene.from_file(path, base_dir=root, device=0)
+    whole.set_canvas(200, 150)
+    want = whole.render(rgb64=False, hit_leaf=False)[0]["rgb8"]
+    host = pkg.Scene.from_file(path, base_dir=root, device=None)
+    host.set_canvas(200, 150)
+    ring = pkg.bindings.HostFrameRing(200, 150, 3)
+    rays = 0
+    for part in range(3):
+        loop = host.frame_loop([0], depth=3, first_part=part, total_parts=3, ring=ring)
+        seconds, stats = loop.run(1, 3, True)
+        rays += sum(s.primary for s in stats)
+        if part < 2:
+            assert not np.array_equal(ring.frame(0), want)  # bands of the parts still to come are missing
+        loop.close()
+    assert rays == 3 * 200 * 150
+    for slot in range(3):
+        assert np.array_equal(ring.frame(slot), want)
+    with pytest.raises(Exception):
+        host.frame_loop([0, 0], depth=3, first_part=2, total_parts=3, ring=ring)  # parts 2 and 3 of 3
+    ring.close()
+
+
 def test_clone_renders_the_same_frame(pkg, root):
     import ctypes as C
     amd, _ = pkg.bindings.libraries()
