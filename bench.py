@@ -253,9 +253,9 @@ def bench_ranks(args, world):
 
     pkg = load_package()
     W, H = args.width, args.height
-    # The frames are assembled in one shared-memory ring when the machine can page-lock a mapping the caller owns
-    # (rt_host_register); where it cannot, every rank keeps its bands in a page-locked ring of its own and the
-    # shared mapping serves only to put the last frame together for the checksum, after the timed region.
+    # Every rank keeps its bands in a page-locked ring of its own; the shared mapping serves to put the last frame
+    # together for the checksum, after the timed region.  With RT_BENCH_SHARED_RING=1 the ranks try to page-lock the
+    # shared mapping itself (rt_host_register) and, when every rank succeeds, copy their bands straight into it.
     name = ["rt_amd_bench_%d_%d" % (os.getpid(), int(time.time()))] if rank == 0 else [None]
     dist.broadcast_object_list(name, src=0)
     shared = pkg.bindings.SharedFrameRing(name[0], W, H, DEPTH, create=True, register=False) if rank == 0 else None
@@ -263,7 +263,7 @@ def bench_ranks(args, world):
     if rank != 0:
         shared = pkg.bindings.SharedFrameRing(name[0], W, H, DEPTH, create=False, register=False)
     pinned = [0]
-    if os.environ.get("RT_BENCH_PRIVATE_RINGS", "0") != "1":
+    if os.environ.get("RT_BENCH_SHARED_RING", "0") == "1":  # opt-in: no machine of this build's pool accepts the registration
         pinned[0] = 1 if shared.register() else 0
     flags = [None] * world
     dist.all_gather_object(flags, pinned[0])
@@ -335,8 +335,9 @@ def bench_ranks(args, world):
                 "rays_per_frame": rays_per_frame,
                 "timed_region": "ray generation to the finished frame in page-locked host memory: " + (
                     "one shared-memory frame that every rank fills with its own bands by DMA" if assembled_by_dma else
-                    "every rank's bands in a page-locked ring of its own (this machine's hipHostRegister refuses to page-lock "
-                    "a shared mapping, so the bands are not assembled in one mapping inside the timed region)"),
+                    "every rank's bands in a page-locked ring of its own (the ranks do not assemble them in one mapping inside "
+                    "the timed region: that needs hipHostRegister on a shared mapping, RT_BENCH_SHARED_RING=1, which the "
+                    "machines this was built on refuse)"),
                 "frame_assembled_by_dma_in_shared_memory": assembled_by_dma,
                 "parallelism": "one rank per GPU, %d parts = bands of 32 pixel rows dealt round-robin, scene replicated, each "
                                "rank copies its bands over its own PCIe link into the shared frame; no collective on the "
