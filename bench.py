@@ -85,6 +85,9 @@ def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
     secondary = counted["reflect"] + counted["refract"]
     records = (counted["primary"] if secondary else 0) + secondary
     hbm = launches * scene_bytes + counted["primary"] * BYTES_PIXEL + 2 * records * RECORD_BYTES
+    # the measurement plan's byte model: every ray, visit, test and hit priced as if its records came from memory
+    rays = counted["primary"] + counted["shadow"] + secondary
+    plan_bytes = rays * (2 * 80 + 2 * 32) + nv * 64 + tt * 72 + qt * 136 + hits * (24 + 200) + launches * scene_bytes
     avg_ms = piped["kernel_ms"] / max(1, piped["kernel_launches"])
     lone_ms = lone["kernel_ms"] / max(1, lone["kernel_launches"])
     per_launch = flops_survey / launches
@@ -115,6 +118,8 @@ def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
         "pmc_f64_ops_per_launch": pmc,
         "frac_pmc_f64": None if not pmc else pmc / (avg_ms * 1e-3) / FP64_VALU_PEAK,
         "hbm_bytes_per_launch": hbm / launches, "frac_hbm": hbm / launches / (avg_ms * 1e-3) / HBM_PEAK,
+        "plan_bytes_per_launch": plan_bytes / launches,
+        "plan_bytes_over_hbm_peak": plan_bytes / launches / (avg_ms * 1e-3) / HBM_PEAK,
         "events_per_frame": {"node_visits": nv, "tri_tests": tt, "quadric_tests": qt, "gate_tests": gt, "shaded_hits": hits},
         "coefficients": {"frac": SURVEY, "f64_this_implementation": F64, "f32_per_node_visit": F32_PER_NODE},
         "note": "no dense contraction on this path, so no MFMA: the ceiling is vector FP64 (78.6 TFLOP/s datasheet, an FMA "
@@ -157,6 +162,31 @@ def bench_single_process(args):
     counted = sum_stats(loop.blocking_frames(1, True))
     piped = sum_stats(host_stats)
     rays_per_frame = (piped["primary"] + piped["shadow"] + piped["reflect"] + piped["refract"]) / args.steps
+    # Beside the metric, for N > 1: whole frames dealt to the GPUs (one single-GPU loop per GPU, each on a thread of
+    # its own; the native loops run without the interpreter lock) instead of one frame cut into N parts.
+    dealt = None
+    if n > 1 and not args.no_dealt_leg and not args.hbm_only:
+        import threading
+        loops = [scene.frame_loop([d], depth=DEPTH) for d in devices]
+        gate = threading.Barrier(n + 1)
+
+        def deal(lp):
+            lp.run(0, PRIMING + args.warmup, True)
+            gate.wait()
+            gate.wait()
+            lp.run(0, args.steps, True)
+
+        threads = [threading.Thread(target=deal, args=(lp,)) for lp in loops]
+        for t in threads:
+            t.start()
+        gate.wait()  # every loop warm, every GPU idle
+        t0 = time.perf_counter()
+        gate.wait()
+        for t in threads:
+            t.join()
+        dealt = time.perf_counter() - t0
+        for lp in loops:
+            lp.close()
     roofline = roofline_of(counted, lone, piped, linfo["scene_bytes"], host_s / args.steps, n)
 
     cpu_baseline = None
@@ -213,6 +243,11 @@ def bench_single_process(args):
         "frames_left_in_hbm": None if hbm_s is None else {
             "value": rays_per_frame * args.steps / hbm_s, "unit": "rays/s", "ms_per_step": hbm_s / args.steps * 1e3,
             "note": "the same loop without the copies to the host (not the metric's timed region)"},
+        "whole_frames_dealt_to_the_gpus": None if dealt is None else {
+            "value": n * rays_per_frame * args.steps / dealt, "unit": "rays/s", "frames_per_step": n,
+            "ms_per_step": dealt / args.steps * 1e3, "scaling": "weak",
+            "note": "not the metric: every GPU renders whole frames of its own and copies them to a page-locked ring of its "
+                    "own (frames of an animation dealt round-robin); the metric above cuts each frame into parts"},
         "PCIe_GBps": W * H * 3 * args.steps / host_s / 1e9,
         "breakdown_ms": {"frame": host_s / args.steps * 1e3, "generation_kernels_per_frame": piped["kernel_ms"] / args.steps,
                          "lone_frame_kernel": lone["kernel_ms"] / 10},
@@ -315,6 +350,22 @@ def bench_ranks(args, world):
     counted_mine = sum_stats(loop.blocking_frames(1, True))
     piped_mine = sum_stats(host_stats)
     piped = all_sum(piped_mine)
+    # Beside the metric: whole frames dealt to the GPUs instead of one frame cut into parts (a step = one frame per
+    # GPU, each rank renders and copies whole frames on its own): what the node delivers when frames are independent.
+    dealt = None
+    if not args.no_dealt_leg:
+        own = pkg.bindings.HostFrameRing(W, H, DEPTH)
+        whole = scene.frame_loop([dev_index], depth=DEPTH, first_part=0, total_parts=1, ring=own)
+        whole.run(0, PRIMING + args.warmup, True)
+        sync()
+        t0 = time.perf_counter()
+        whole.run(0, args.steps, True)
+        sync()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dealt = float(dt.item())
+        whole.close()
+        own.close()
     rays_per_frame = (piped["primary"] + piped["shadow"] + piped["reflect"] + piped["refract"]) / args.steps
     roofline = roofline_of(counted_mine, lone_mine, piped_mine, linfo["scene_bytes"], host_s / args.steps, 1)
     roofline["scope"] = "rank 0's part of the frame"
@@ -347,6 +398,11 @@ def bench_ranks(args, world):
             "frames_left_in_hbm": None if hbm_s is None else {
                 "value": rays_per_frame * args.steps / hbm_s, "unit": "rays/s", "ms_per_step": hbm_s / args.steps * 1e3,
                 "note": "the same loop without the copies to the host (not the metric's timed region)"},
+            "whole_frames_dealt_to_the_gpus": None if dealt is None else {
+                "value": world * rays_per_frame * args.steps / dealt, "unit": "rays/s", "frames_per_step": world,
+                "ms_per_step": dealt / args.steps * 1e3, "scaling": "weak",
+                "note": "not the metric: every GPU renders whole frames of its own and copies them to its own page-locked "
+                        "ring (frames of an animation dealt round-robin); the metric above cuts each frame into parts"},
             "PCIe_GBps": W * H * 3 * args.steps / host_s / 1e9,
             "pipeline": {"frames_in_flight_per_gpu": DEPTH, "untimed_priming_frames": PRIMING},
             "frame_sha256": sha,
@@ -498,6 +554,8 @@ def main():
     ap.add_argument("--hbm-only", action="store_true",
                     help="time only the loop that leaves the frames in HBM (for profiler runs: under rocprofv3 the runtime "
                          "turns the DMA copies to the host into copy kernels that share the GPU with the render kernel)")
+    ap.add_argument("--no-dealt-leg", action="store_true",
+                    help="N > 1: skip the extra leg that deals whole frames to the GPUs")
     ap.add_argument("--rccl-gather", action="store_true",
                     help="under a launcher with one rank per GPU: gather the parts on rank 0 with RCCL instead of "
                          "letting every rank copy its bands into the shared host frame")
