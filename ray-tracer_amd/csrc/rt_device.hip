@@ -2302,7 +2302,7 @@ extern "C" int rt_device_count(void) {
 extern "C" void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  // frames may still run on either render stream and copies on the copy stream: drain all three
+  // frames may still run on any render stream and copies on the copy stream: drain them all
   // before any of the memory they use is released
   for (hipStream_t st : {s->stream, s->frame_stream[0], s->frame_stream[1], s->frame_stream[2], s->copy_stream})
     if (st) (void)hipStreamSynchronize(st);
@@ -3724,8 +3724,8 @@ extern "C" int rt_scene_copy_stream(rt_scene* s, void** hip_stream) {
   return RT_OK;
 }
 
-// The copy stream waits for everything enqueued so far on after_stream, or, when none is given, on both
-// render streams (asynchronous frames alternate between them).
+// The copy stream waits for everything enqueued so far on after_stream or, when none is given, on every render
+// stream that has had work enqueued since the copy stream was last ordered after it.
 static int order_copy_stream(rt_scene* s, void* after_stream) {
   if (after_stream) {
     HIP_TRY(hipEventRecord(s->copy_order, (hipStream_t)after_stream));
