@@ -41,7 +41,7 @@ F32_PER_NODE = 4 * 11
 BYTES_PIXEL = 3
 RECORD_BYTES = 13 * 8 + 4 * 4  # one ray record of a generation buffer
 
-DEPTH = 4     # frames in flight per GPU = host frames in the ring
+DEPTH = int(os.environ.get("RT_BENCH_DEPTH", "4"))  # frames in flight per GPU = host frames in the ring
 PRIMING = 64  # untimed frames before the warmup: first launches load code objects and grow runtime pools
 
 

@@ -1252,6 +1252,9 @@ DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y
 #ifndef RT_MIN_WAVES_SPAWN
 #define RT_MIN_WAVES_SPAWN 3
 #endif
+#ifndef RT_SHADOW_ALWAYS
+#define RT_SHADOW_ALWAYS 0  // 1: traverse every shadow query, also those whose answer cannot reach the colour (A/B builds)
+#endif
 template <int STACK, bool COUNT, int MODE, bool CSG, bool UNIFORM>
 __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES_SPAWN)
     k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_segcap, int remaining,
@@ -1475,7 +1478,15 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
     SQ.distance = magnitude(v);
     SQ.found = false;
     Ray shadow_ray{over_point, normalize(v)};
-    traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM>, COUNT>(S, shadow_ray, SQ, st, cs);
+    // lighting() returns `ambient` in shadow and `ambient + diffuse + specular` otherwise
+    // (src/light.rs:135-173).  Where the two are the same bits -- the light behind the surface, or a
+    // material without diffuse and specular terms -- the answer of is_shadowed cannot reach the
+    // colour, and the query (still counted as a ray) is not traversed.
+    const bool decides = __double_as_longlong(ar) != __double_as_longlong(lr) ||
+                         __double_as_longlong(ag) != __double_as_longlong(lg) ||
+                         __double_as_longlong(ab) != __double_as_longlong(lb);
+    if (RT_SHADOW_ALWAYS || decides)
+      traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM>, COUNT>(S, shadow_ray, SQ, st, cs);
     out_r = SQ.found ? ar : lr;
     out_g = SQ.found ? ag : lg;
     out_b = SQ.found ? ab : lb;

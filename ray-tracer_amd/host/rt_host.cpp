@@ -1221,20 +1221,38 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
   Rendezvous meet(workers);
   std::chrono::steady_clock::time_point t0, t1;
   const size_t w = cam_.hsize, rows_total = cam_.vsize, band_bytes = (size_t)32 * w * 3;
+  // A fence on the copy stream after every copy costs about 5 us of the copy engine's time (the next
+  // copy starts only when the fence's marker has gone through the stream's queue).  Copies on one stream
+  // finish in order, so a fence after every `stride`-th copy tells as much: a slot is free once a fence
+  // recorded at or after its copy has passed.  stride <= depth - 1 keeps the fence a frame waits for
+  // recorded before that frame is enqueued, with at least one other slot to render into meanwhile.
+  size_t stride = depth_ >= 3 ? 2 : 1;
+  if (const char* e = getenv("RT_AMD_COPIES_PER_FENCE")) stride = (size_t)std::max(1, atoi(e));
+  stride = std::min(stride, (size_t)std::max(1, depth_ - 1));
   auto worker = [&](size_t k) {
     rt_scene* sc = scenes_[k];
     const size_t part = first_part_ + k;
     bool ok = true;
+    std::vector<int> fenced_by((size_t)depth_, -1);  // per slot: the slot whose fence covers this slot's last copy
+    std::vector<int> unfenced;                        // slots copied since the last fence
+    size_t last_frame = 0;                            // of the stretch of frames being enqueued
     auto frame = [&](size_t f) {
       if (!ok) return;
       const int slot = (int)(f % (size_t)depth_);
       uint8_t* dev = dev_frames_[k][(size_t)slot];
       // the copy that last read this device frame (depth frames ago) must be through before it is rendered over
-      if (to_host && rt_copy_wait(sc, (uint32_t)slot) != RT_OK) ok = false;
+      if (to_host && fenced_by[(size_t)slot] >= 0 && rt_copy_wait(sc, (uint32_t)fenced_by[(size_t)slot]) != RT_OK) ok = false;
       if (ok && rt_render(sc, &cam_, (int)part, (int)n, RT_FLAG_ASYNC | RT_FLAG_BANDS, dev, nullptr, nullptr, nullptr) != RT_OK) ok = false;
+      auto fence = [&]() {  // after this slot's copy has been enqueued
+        unfenced.push_back(slot);
+        if (unfenced.size() < stride && f != last_frame) return;
+        if (rt_copy_fence(sc, (uint32_t)slot) != RT_OK) ok = false;
+        for (int s : unfenced) fenced_by[(size_t)s] = slot;
+        unfenced.clear();
+      };
       if (ok && to_host && n == 1) {  // the whole frame is this part's: one contiguous copy
         if (rt_download(sc, dev, host_[(size_t)slot], frame_bytes_, nullptr) != RT_OK) ok = false;
-        if (ok && rt_copy_fence(sc, (uint32_t)slot) != RT_OK) ok = false;
+        if (ok) fence();
       } else if (ok && to_host) {
         // this part's bands: whole bands with one strided copy, a last partial band with a plain one
         const size_t first = part * 32, n_bands_mine = first < rows_total ? (rows_total - first + n * 32 - 1) / (n * 32) : 0;
@@ -1247,10 +1265,11 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
           const size_t y0 = first + whole * n * 32, o = y0 * w * 3;
           if (rt_download(sc, dev + o, host + o, (rows_total - y0) * w * 3, nullptr) != RT_OK) ok = false;
         }
-        if (ok && rt_copy_fence(sc, (uint32_t)slot) != RT_OK) ok = false;
+        if (ok) fence();
       }
       if (!ok) errors[k] = rt_last_error();
     };
+    last_frame = warmup ? warmup - 1 : 0;
     for (size_t f = 0; f < warmup; f++) frame(f);
     rt_stats st{};
     if (ok && rt_scene_wait(sc, &st) != RT_OK) {
@@ -1259,6 +1278,7 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     }
     meet.arrive_and_wait();  // every GPU idle, every worker ready
     if (k == 0) t0 = std::chrono::steady_clock::now();
+    last_frame = warmup + frames - 1;
     for (size_t f = 0; f < frames; f++) frame(warmup + f);
     if (ok && rt_scene_wait(sc, &result.part[k]) != RT_OK) {  // rendered and, with to_host, on the host
       ok = false;
