@@ -43,7 +43,7 @@ static_assert(BAND_GRID_CEILING <= (1 << 14) / 2, "walk() packs cell offsets int
 
 int band_grid_first_n(size_t n_bands) {
   static const int n_max = [] {
-    int v = 4096;
+    int v = 1024;
     if (const char* e = getenv("RT_AMD_BAND_GRID_MAX")) v = atoi(e);
     v = std::max(BAND_GRID_MIN, std::min(BAND_GRID_CEILING, v));
     int p = BAND_GRID_MIN;
@@ -95,6 +95,7 @@ BandGrid build_band_grid(const std::vector<ConeBand>& bands, size_t max_items) {
     }
     grid.start[cells] = run;
     grid.items.resize(total);
+    grid.strip.resize(total);
     each_band([&](size_t i) {
       raster_band(bands[i], n, [&](int cell) {
         grid.items[count[cell].fetch_add(1, std::memory_order_relaxed)] = (uint32_t)i;
@@ -108,8 +109,14 @@ BandGrid build_band_grid(const std::vector<ConeBand>& bands, size_t max_items) {
         for (;;) {
           size_t lo = next.fetch_add(4096);
           if (lo >= cells) return;
-          for (size_t c = lo; c < std::min(cells, lo + 4096); c++)
+          for (size_t c = lo; c < std::min(cells, lo + 4096); c++) {
             std::sort(grid.items.begin() + grid.start[c], grid.items.begin() + grid.start[c + 1]);
+            const int face = (int)(c / ((size_t)n * n)), iv = (int)((c / (size_t)n) % (size_t)n), iu = (int)(c % (size_t)n);
+            for (uint32_t k = grid.start[c]; k < grid.start[c + 1]; k++) {
+              const ConeBand& b = bands[grid.items[k]];
+              grid.strip[k] = band_strip_word(face_poly(b, face), band_threshold(b), n, iu, iv);
+            }
+          }
         }
       });
     for (auto& t : pool) t.join();

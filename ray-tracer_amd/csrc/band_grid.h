@@ -15,6 +15,7 @@ struct BandGrid {
   int n = 0;                    // cells per side of one face; 0 = no grid (scan the list)
   std::vector<uint32_t> start;  // 3 n n + 1 offsets into items, cell = (axis n + iv) n + iu
   std::vector<uint32_t> items;  // band indices
+  std::vector<uint32_t> strip;  // per entry: where in the cell the band lies (band_strip_word, band_grid_test.h)
 };
 
 // Builds the grid for bands (empty grid when there are few of them).  max_items bounds the memory:
@@ -30,6 +31,11 @@ int band_grid_first_n(size_t n_bands);
 // there are too few bands for a grid.  Returns 0 or a negative rt_status (rt_last_error() says why).
 int build_band_grid_device(const ConeBand* d_bands, size_t n_bands, size_t max_items, int* n_out, uint32_t** d_start,
                            uint32_t** d_items, size_t* n_items);
+
+// The strip words of a grid on the device (one per entry, in the entries' order): *out is a new
+// hipMalloc'ed array of n_items words.  Returns 0 or a negative rt_status.
+int build_band_strips_device(const ConeBand* d_bands, int n, const uint32_t* d_start, const uint32_t* d_items, size_t n_items,
+                             uint32_t** out);
 
 // The entries of a grid on the device as 16-bit numbers (for fewer than 65536 bands): *out is a new
 // hipMalloc'ed array of n_items entries, d_items is freed.  Returns 0 or a negative rt_status.

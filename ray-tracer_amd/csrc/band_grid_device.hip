@@ -236,6 +236,41 @@ done:
   return rc;
 }
 
+// The strip word of every entry: one thread per cell walks the cell's entries.
+namespace {
+__global__ void __launch_bounds__(THREADS) k_strips(const ConeBand* bands, int n, const uint32_t* start, const uint32_t* items,
+                                                    uint32_t n_cells, uint32_t* strip) {
+  const uint32_t c = blockIdx.x * THREADS + threadIdx.x;
+  if (c >= n_cells) return;
+  const uint32_t nn = (uint32_t)n * (uint32_t)n;
+  const int face = (int)(c / nn), iv = (int)((c % nn) / (uint32_t)n), iu = (int)(c % (uint32_t)n);
+  for (uint32_t k = start[c]; k < start[c + 1]; k++) {
+    const ConeBand b = bands[items[k]];
+    strip[k] = band_strip_word(face_poly(b, face), band_threshold(b), n, iu, iv);
+  }
+}
+}  // namespace
+
+int build_band_strips_device(const ConeBand* d_bands, int n, const uint32_t* d_start, const uint32_t* d_items, size_t n_items,
+                             uint32_t** out) {
+  *out = nullptr;
+  uint32_t* p = nullptr;
+  hipError_t e = hipMalloc((void**)&p, (n_items + 4) * sizeof(uint32_t));  // a ray reads four words at a time
+  if (e != hipSuccess) return rt_fail_message(RT_ERR_NOMEM, "no device memory for the cone direction index");
+  e = hipMemset(p, 0, (n_items + 4) * sizeof(uint32_t));
+  const uint32_t cells = 3u * (uint32_t)n * (uint32_t)n;
+  if (e == hipSuccess && n_items)
+    hipLaunchKernelGGL(k_strips, dim3((cells + THREADS - 1) / THREADS), dim3(THREADS), 0, 0, d_bands, n, d_start, d_items, cells, p);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return rt_fail_message(RT_ERR_DEVICE, (std::string("k_strips: ") + hipGetErrorString(e)).c_str());
+  }
+  *out = p;
+  return RT_OK;
+}
+
 // The entries of a finished index as 16-bit numbers (for fewer than 65536 cones): half the memory, and
 // half the bytes a ray reads per entry.  Frees the 32-bit array.
 namespace {
@@ -338,8 +373,23 @@ extern "C" int rt_selftest_band_grid_device(int n_bands, uint64_t seed, int devi
     (void)hipMemcpy(start.data(), d_start, start.size() * 4, hipMemcpyDeviceToHost);
     if (!items.empty()) (void)hipMemcpy(items.data(), d_items, items.size() * 4, hipMemcpyDeviceToHost);
     differ = (start != host.start || items != host.items) ? 1 : 0;
+    if (!differ) {  // the strip words, computed on the device from the device's own index
+      uint32_t* d_strip = nullptr;
+      ConeBand* d_again = nullptr;
+      if (hipMalloc(&d_again, (bands.size() + 1) * sizeof(ConeBand)) != hipSuccess) return rt_fail_message(RT_ERR_DEVICE, "hipMalloc failed");
+      (void)hipMemcpy(d_again, bands.data(), bands.size() * sizeof(ConeBand), hipMemcpyHostToDevice);
+      rc = build_band_strips_device(d_again, n, d_start, d_items, n_items, &d_strip);
+      (void)hipFree(d_again);
+      if (rc == RT_OK) {
+        std::vector<uint32_t> strip(host.strip.size());
+        if (!strip.empty()) (void)hipMemcpy(strip.data(), d_strip, strip.size() * 4, hipMemcpyDeviceToHost);
+        differ = strip != host.strip ? 1 : 0;
+        (void)hipFree(d_strip);
+      }
+    }
   }
   if (d_start) (void)hipFree(d_start);
   if (d_items) (void)hipFree(d_items);
+  if (rc != RT_OK) return rc;
   return differ;
 }

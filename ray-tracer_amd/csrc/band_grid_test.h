@@ -3,6 +3,8 @@
 // this one definition (without multiply-add contraction).
 #pragma once
 #include <math.h>
+#include <stdint.h>
+#include <string.h>
 
 #include "rt_types.h"
 
@@ -43,6 +45,98 @@ RT_HD bool band_cell_passes(const FacePoly& p, double thr, int level_n, int iu, 
   const double reach = (fabs(gu) + fabs(gv)) * h + (fabs(p.cuu) + fabs(p.cuv) + fabs(p.cvv)) * h * h;
   const double um = fabs(uc) + h, vm = fabs(vc) + h;
   return !(fabs(g) > reach + thr * (1.0 + um * um + vm * vm));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strip word of one (band, cell) entry.  Inside a cell the band is close to a straight strip: with
+// cell-local coordinates s, t in [-1, 1] (u = uc + s / n, v = vc + t / n) and the expansion of g
+// about the cell centre,  g(u, v) = g + gu du + gv dv + second-order part,  a direction of the cell
+// can lie in the band only if  |g + gu du + gv dv| <= thr (1 + um^2 + vm^2) + (|cuu| + |cuv| + |cvv|) h^2.
+// Divided by the larger of |gu|, |gv| (times the half cell size) that reads |g0 + a + m b| <= w with a
+// the coordinate of the larger coefficient, b the other one and |m| <= 1.  The word keeps g0 (12 bits,
+// steps of 1/512), m (11 bits, steps of 1/1024), w rounded up to an 8-bit float and which coordinate a
+// is; w also takes up the rounding of g0 and m and what the ray's single-precision s, t can be off by.
+// A ray tests the word of every entry of its cell (one multiply-add and a compare) and only looks up
+// the bands whose strip it lies in: a few per cent of the entries.
+//   bits 31..20 g0, 19..9 m, 8..1 width code, 0: 1 when a = t.
+constexpr uint32_t BAND_STRIP_ALWAYS = 0xFFu;  // width code: every direction of the cell passes
+
+// Width code c < 255 stands for 2^(c / 16 - 11) (1 + (c % 16) / 16): the f32 with bit pattern
+// (c << 19) + (116 << 23).
+RT_HD double band_strip_width(uint32_t code) {
+  double v = 1.0 + (double)(code & 15u) / 16.0;
+  int e = (int)(code >> 4) - 11;
+  for (; e > 0; e--) v *= 2.0;
+  for (; e < 0; e++) v *= 0.5;
+  return v;
+}
+RT_HD uint32_t band_strip_width_code(double w) {  // the smallest code whose width is >= w
+  if (!(w > 0.00048828125)) return 0u;            // 2^-11
+  uint32_t e = 0;
+  double base = 0.00048828125;
+  while (e < 15u && w >= base * 2.0) {
+    base *= 2.0;
+    e++;
+  }
+  if (w >= base * 2.0) return BAND_STRIP_ALWAYS;
+  const double f = (w / base - 1.0) * 16.0;  // in [0, 16)
+  uint32_t mant = (uint32_t)f;
+  if ((double)mant < f) mant++;
+  uint32_t code = (e << 4) + mant;  // mant == 16 carries into the exponent
+  return code >= BAND_STRIP_ALWAYS ? BAND_STRIP_ALWAYS : code;
+}
+
+// What a ray's s, t (computed in single precision from the direction rounded to f32, band_strip_coords)
+// can differ by from the exact local coordinates, for an n x n face.
+RT_HD double band_strip_coord_error(int n) { return 1.0e-3 * ((double)n / 1024.0) + 1e-5; }
+
+RT_HD uint32_t band_strip_word(const FacePoly& p, double thr, int n, int iu, int iv) {
+  const double size = 2.0 / n;
+  const double h = 0.5 * size * (1.0 + 1e-9) + 2e-6;  // as in band_cell_passes: the cell the lookup may pick
+  const double hn = 0.5 * size;
+  const double uc = -1.0 + (iu + 0.5) * size, vc = -1.0 + (iv + 0.5) * size;
+  const double g = p.c0 + p.cu * uc + p.cv * vc + p.cuu * uc * uc + p.cuv * uc * vc + p.cvv * vc * vc;
+  const double gu = p.cu + 2.0 * p.cuu * uc + p.cuv * vc, gv = p.cv + 2.0 * p.cvv * vc + p.cuv * uc;
+  const double um = fabs(uc) + h, vm = fabs(vc) + h;
+  const double w = thr * (1.0 + um * um + vm * vm) + (fabs(p.cuu) + fabs(p.cuv) + fabs(p.cvv)) * h * h;
+  const double du = gu * hn, dv = gv * hn;
+  const uint32_t which = fabs(dv) > fabs(du) ? 1u : 0u;
+  const double major = which ? dv : du, minor = which ? du : dv;
+  const uint32_t always = BAND_STRIP_ALWAYS << 1;
+  if (!(fabs(major) > 1e-300)) return always;
+  const double g0 = g / major, m = minor / major, wn = w / fabs(major);
+  if (!(wn < 3.0) || !(fabs(g0) < 3.9)) return always;
+  double q0 = floor(g0 * 512.0 + 0.5), qm = floor(m * 1024.0 + 0.5);
+  q0 = q0 < -2048.0 ? -2048.0 : (q0 > 2047.0 ? 2047.0 : q0);
+  qm = qm < -1024.0 ? -1024.0 : (qm > 1023.0 ? 1023.0 : qm);
+  const double e0 = fabs(g0 - q0 / 512.0), em = fabs(m - qm / 1024.0);
+  const double reach = h / hn;  // how far s, t of a direction of the (padded) cell can go
+  const double delta = band_strip_coord_error(n);
+  const double slack = e0 + em * reach + delta * (1.0 + fabs(qm / 1024.0)) + 1e-5;
+  const uint32_t code = band_strip_width_code(wn + slack);
+  if (code >= BAND_STRIP_ALWAYS) return always;
+  return (((uint32_t)(int)q0 & 0xFFFu) << 20) | (((uint32_t)(int)qm & 0x7FFu) << 9) | (code << 1) | which;
+}
+
+// The ray's side.  (x, y): the direction's face coordinates in cell units, in [0, n]; the cell index and
+// the local coordinates come from the same rounded values.
+RT_HD void band_strip_coords(float x, float y, int n, int& iu, int& iv, float& s, float& t) {
+  iu = (int)floorf(x);
+  iv = (int)floorf(y);
+  iu = iu < 0 ? 0 : (iu >= n ? n - 1 : iu);
+  iv = iv < 0 ? 0 : (iv >= n ? n - 1 : iv);
+  s = 2.0f * (x - (float)iu) - 1.0f;
+  t = 2.0f * (y - (float)iv) - 1.0f;
+}
+RT_HD bool band_strip_passes(uint32_t word, float s, float t) {
+  const uint32_t code = (word >> 1) & 0xFFu;
+  const float g0 = (float)((int32_t)word >> 20) * (1.0f / 512.0f);
+  const float m = (float)((int32_t)(word << 12) >> 21) * (1.0f / 1024.0f);
+  const uint32_t wbits = (code << 19) + (116u << 23);
+  float w;
+  memcpy(&w, &wbits, 4);
+  const float a = (word & 1u) ? t : s, b = (word & 1u) ? s : t;
+  return code == BAND_STRIP_ALWAYS || fabsf((g0 + a) + m * b) <= w;
 }
 
 }  // namespace rt

@@ -39,6 +39,7 @@
 
 #include "../../include/rt_amd.h"
 #include "band_grid.h"
+#include "band_grid_test.h"
 #include "bvh_build.h"
 #include "rt_error.h"
 #include "rt_types.h"
@@ -470,6 +471,8 @@ struct LdsStack {
     sp += take ? 1 : 0;
   }
   DEV uint32_t pop() { return base[(--sp) * BLOCK]; }
+  DEV uint32_t peek(int i) const { return base[i * BLOCK]; }  // entry i of this lane's column, used as a queue
+  DEV void poke(int i, uint32_t r) { base[i * BLOCK] = r; }
   DEV uint32_t pop_or_none() { return sp > 0 ? base[(--sp) * BLOCK] : REF_NONE; }
   DEV bool empty() const { return sp == 0; }
   DEV void clear() { sp = 0; }
@@ -498,6 +501,8 @@ struct LdsStack {
     sp += take ? 1 : 0;
   }
   DEV uint32_t pop() { return slot[--sp]; }
+  DEV uint32_t peek(int i) const { return slot[i]; }
+  DEV void poke(int i, uint32_t r) { slot[i] = r; }
   DEV uint32_t pop_or_none() { return sp > 0 ? slot[--sp] : REF_NONE; }
   DEV bool empty() const { return sp == 0; }
   DEV void clear() { sp = 0; }
@@ -585,26 +590,35 @@ DEV void slab4(const RayBox& rb, float qhi, const F4& nx, const F4& ny, const F4
   }
 }
 
-template <class Query, bool GENERAL>
-DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& Q, bool check_gates) {
+struct __attribute__((packed, aligned(4))) StripWords {  // four strip words of a cell's list, at any word address
+  uint32_t x, y, z, w;
+};
+
+// The intersections of one primitive with a world-space ray, its enclosing groups' gates included when
+// asked for: how many (0..4), written to t in the reference's emission order.
+template <bool GENERAL>
+DEV int eval_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, double t[4], bool check_gates) {
   if (check_gates) {
     for (int g = q.gate; g >= 0; g = S.gates[g].parent)
-      if (!gate_passes<GENERAL>(S, S.gates[g], ray)) return;
+      if (!gate_passes<GENERAL>(S, S.gates[g], ray)) return 0;
   }
-  double t[4];
 #ifndef RT_NO_PLANE_FAST
   if (q.type == RT_PLANE) {
     // only the y row of the transformed ray enters intersect_plane (src/shape.rs:891-908)
     const double oy = q.m[4] * ray.o.x + q.m[5] * ray.o.y + q.m[6] * ray.o.z + q.m[7];
     const double dy = q.m[4] * ray.d.x + q.m[5] * ray.d.y + q.m[6] * ray.d.z;
-    if (fabs(dy) <= FEQ_EPSILON) return;
+    if (fabs(dy) <= FEQ_EPSILON) return 0;
     t[0] = -oy / dy;
-    Q.leaf_ts(q.leaf, 1, t);
-    return;
+    return 1;
   }
 #endif
   Ray local = quad_ray<GENERAL>(S, q, ray);  // src/shape.rs:1468
-  int n = intersect_quadric(q.type, q.closed, q.minimum, q.maximum, local, t);
+  return intersect_quadric(q.type, q.closed, q.minimum, q.maximum, local, t);
+}
+template <class Query, bool GENERAL>
+DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& Q, bool check_gates) {
+  double t[4];
+  const int n = eval_quad<GENERAL>(S, q, ray, t, check_gates);
   if (n) Q.leaf_ts(q.leaf, n, t);
 }
 
@@ -753,51 +767,81 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       const float dc = m == 0 ? fz : (m == 1 ? fx : fy);
       const float inv = __builtin_amdgcn_rcpf(dm);
       const float half_n = 0.5f * (float)n;
-      int iu = (int)floorf((da * inv + 1.0f) * half_n), iv = (int)floorf((dc * inv + 1.0f) * half_n);
-      iu = iu < 0 ? 0 : (iu >= n ? n - 1 : iu);
-      iv = iv < 0 ? 0 : (iv >= n ? n - 1 : iv);
+      int iu, iv;
+      float ls, lt;  // where in its cell the direction lies, -1..1 per axis
+      band_strip_coords((da * inv + 1.0f) * half_n, (dc * inv + 1.0f) * half_n, n, iu, iv, ls, lt);
       const uint32_t cell = ((uint32_t)m * n + iv) * n + iu;
-      // A cell lists every cone whose band crosses it (16 on average with 25 000 cones); the direction
-      // lies inside about one band in sixty.  Testing a cone the moment one lane finds it would run
-      // the intersection code for the whole wave about as often as there are list entries (some lane
-      // finds one at almost every step), so the lanes only queue what they find (the traversal stack
-      // is free until the hierarchy is walked) and then work through their queues in step: the
-      // intersection code runs as often as the fullest queue is long.  The filter runs in single
-      // precision (it passes slightly more than the double-precision band; the cone's own test
-      // decides, src/shape.rs:1089) and keeps few registers alive, so that scenes without cones do
-      // not pay for it in spills.
+      // A cell lists every cone whose band crosses it, and with each entry a word that says where in the
+      // cell the band lies (a strip, band_grid_test.h).  Three passes, each over all lanes in step, because
+      // what is rare for one ray happens in every wave:
+      //   1. the strip words of the cell, four per load from one contiguous array: one multiply-add and a
+      //      compare per entry, no look-up; the few entries whose strip holds the direction are queued on
+      //      the traversal stack (free until the hierarchy is walked);
+      //   2. the queued entries: band number, then the band's quadratic form in single precision (it passes
+      //      slightly more than the double-precision band); survivors stay queued as primitive numbers;
+      //   3. the cone's own test (src/shape.rs:1089) for what is left: it runs as often as the fullest
+      //      queue is long, not once per entry some lane happens to pass.  (Dealing these tests evenly over
+      //      the lanes of the wave through LDS was measured and is no faster: with 25 000 cones the tests
+      //      are 1.3 ms of a 15.7 ms frame.)
       const uint32_t end = S.band_start[cell + 1];
+#ifdef RT_DIAG_NO_BANDS  // timing builds (wrong frames): the passes below stop after the cell look-up (0) .. run in full (3)
+      const int band_passes = S.band_diag_passes;
+#else
+      constexpr int band_passes = 3;
+#endif
       const float fdd = (fxx + fyy + fzz) * (1.0f + 1e-6f);
+      const uint16_t* items16 = reinterpret_cast<const uint16_t*>(S.band_items);
       st.clear();
-      auto drain = [&]() {
+      auto flush = [&]() {
+        if (band_passes <= 1) { st.sp = 0; return; }
+        int wp = 0;  // survivors are written over the entries already read (wp <= rp)
+        for (int rp = 0; __any(rp < st.sp); rp += RT_BAND_BATCH) {
+          uint32_t id[RT_BAND_BATCH];
+          ConeBandF32 f[RT_BAND_BATCH];
+#pragma unroll
+          for (int j = 0; j < RT_BAND_BATCH; j++) {
+            const uint32_t at = rp + j < st.sp ? st.peek(rp + j) : 0u;  // entry 0 exists: the index is not empty
+            id[j] = S.band_items16 ? (uint32_t)items16[at] : S.band_items[at];
+          }
+#pragma unroll
+          for (int j = 0; j < RT_BAND_BATCH; j++) f[j] = S.bands32[id[j]];
+#pragma unroll
+          for (int j = 0; j < RT_BAND_BATCH; j++) {
+            const float a = fmaf(f[j].q[0], fxx, fmaf(f[j].q[1], fyy, fmaf(f[j].q[2], fzz,
+                            fmaf(f[j].q[3], fxy, fmaf(f[j].q[4], fxz, f[j].q[5] * fyz)))));
+            if (rp + j < st.sp && fabsf(a) < 1.0001e-4f + f[j].slack * fdd) st.poke(wp++, f[j].prim);
+          }
+        }
+        st.sp = wp;
+        if (band_passes <= 2) st.sp = 0;
+#ifdef RT_DIAG_NO_BANDS
+        Query dropped = Q;  // RT_AMD_TIMING_BAND_PASSES=4: the tests run, their intersections are dropped
+#endif
         while (__any(st.sp > 0)) {
           if (st.sp > 0) {
             const uint32_t prim = st.pop();
             if (COUNT) cnt.quad_tests++;
+#ifdef RT_DIAG_NO_BANDS
+            if (band_passes == 4) test_quad<Query, Stack::WITH_CSG>(S, S.band_prims[prim], ray, dropped, true);
+            else
+#endif
             test_quad<Query, Stack::WITH_CSG>(S, S.band_prims[prim], ray, Q, true);
           }
         }
       };
-      const uint16_t* items16 = reinterpret_cast<const uint16_t*>(S.band_items);
-      for (uint32_t k = S.band_start[cell]; k < end; k += RT_BAND_BATCH) {
-        uint32_t id[RT_BAND_BATCH];
-        ConeBandF32 f[RT_BAND_BATCH];
-#pragma unroll
-        for (int j = 0; j < RT_BAND_BATCH; j++) {
-          const uint32_t at = min(k + j, end - 1);
-          id[j] = S.band_items16 ? (uint32_t)items16[at] : S.band_items[at];
-        }
-#pragma unroll
-        for (int j = 0; j < RT_BAND_BATCH; j++) f[j] = S.bands32[id[j]];
-        if (__any(st.sp + RT_BAND_BATCH > Stack::ENTRIES)) drain();
-#pragma unroll
-        for (int j = 0; j < RT_BAND_BATCH; j++) {
-          const float a = fmaf(f[j].q[0], fxx, fmaf(f[j].q[1], fyy, fmaf(f[j].q[2], fzz,
-                          fmaf(f[j].q[3], fxy, fmaf(f[j].q[4], fxz, f[j].q[5] * fyz)))));
-          if (k + j < end && fabsf(a) < 1.0001e-4f + f[j].slack * fdd) st.push(f[j].prim);
-        }
+      const uint32_t begin = S.band_start[cell];
+      uint32_t stop = end;
+      if (band_passes == 0 && end != 0xFFFFFFFFu) stop = begin;  // the offsets are still fetched
+      // all lanes stay in the loop until the longest list is through: flush() works on the whole wave
+      for (uint32_t k = begin; __any(k < stop); k += 4) {
+        const StripWords w = *reinterpret_cast<const StripWords*>(S.band_strip + (k < stop ? k : stop));  // padded by four words
+        if (__any(st.sp + 4 > Stack::ENTRIES)) flush();
+        st.push_if(k, k < stop && band_strip_passes(w.x, ls, lt));  // room for four was made above
+        st.push_if(k + 1, k + 1 < stop && band_strip_passes(w.y, ls, lt));
+        st.push_if(k + 2, k + 2 < stop && band_strip_passes(w.z, ls, lt));
+        st.push_if(k + 3, k + 3 < stop && band_strip_passes(w.w, ls, lt));
       }
-      drain();
+      flush();
     } else {
       const double xx = ray.d.x * ray.d.x, yy = ray.d.y * ray.d.y, zz = ray.d.z * ray.d.z;
       const double xy = ray.d.x * ray.d.y, xz = ray.d.x * ray.d.z, yz = ray.d.y * ray.d.z;
@@ -2601,12 +2645,15 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
   s->dev.n_bands = (int32_t)b.bands.size();
 #ifdef RT_DIAG_NO_BANDS  // diagnostic builds only (timing of the band list): drops the cones' parallel-ray hits
   if (getenv("RT_AMD_TIMING_NO_BANDS")) s->dev.n_bands = 0;
+  s->dev.band_diag_passes = getenv("RT_AMD_TIMING_BAND_PASSES") ? atoi(getenv("RT_AMD_TIMING_BAND_PASSES")) : 3;
 #endif
   if (getenv("RT_AMD_BAND_GRID_HOST")) {  // the host builder (what the device builder is checked against)
     BandGrid grid = build_band_grid(b.bands, (size_t)1 << 29);  // at most 2 GiB of entries
     s->dev.band_grid_n = grid.n;
     if ((rc = upload(s, grid.start, &s->dev.band_start))) return rc;
     if ((rc = upload(s, grid.items, &s->dev.band_items))) return rc;
+    grid.strip.resize(grid.strip.size() + 4, 0u);  // a ray reads four words at a time
+    if ((rc = upload(s, grid.strip, &s->dev.band_strip))) return rc;
     if (getenv("RT_AMD_DEBUG"))
       fprintf(stderr, "[rt_amd] band grid n=%d cells=%zu entries=%zu\n", grid.n, grid.start.size(), grid.items.size());
   } else {
@@ -2715,7 +2762,7 @@ extern "C" int rt_scene_create_with(const rt_scene_desc* desc, int device, uint3
 // on the scene (16-bit entries when the band numbers fit).
 static int attach_band_grid(rt_scene* s, size_t n_bands) {
   s->dev.band_grid_n = 0;
-  s->dev.band_start = s->dev.band_items = nullptr;
+  s->dev.band_start = s->dev.band_items = s->dev.band_strip = nullptr;
   s->dev.band_items16 = 0;
   int n = 0;
   uint32_t *d_start = nullptr, *d_items = nullptr;
@@ -2723,11 +2770,18 @@ static int attach_band_grid(rt_scene* s, size_t n_bands) {
   int rc = build_band_grid_device(s->dev.bands, n_bands, (size_t)1 << 30, &n, &d_start, &d_items, &n_items);
   if (rc) return rc;
   size_t item_bytes = (n_items + 1) * 4;
+  uint32_t* d_strip = nullptr;
+  if (d_items && (rc = build_band_strips_device(s->dev.bands, n, d_start, d_items, n_items, &d_strip))) {
+    (void)hipFree(d_items);
+    if (d_start) (void)hipFree(d_start);
+    return rc;
+  }
   if (d_items && n_bands < 65536) {
     uint16_t* small = nullptr;
     if ((rc = compress_band_items_u16(d_items, n_items, &small))) {
       (void)hipFree(d_items);
       if (d_start) (void)hipFree(d_start);
+      if (d_strip) (void)hipFree(d_strip);
       return rc;
     }
     d_items = reinterpret_cast<uint32_t*>(small);
@@ -2744,6 +2798,11 @@ static int attach_band_grid(rt_scene* s, size_t n_bands) {
   if (d_items) {
     s->allocs.push_back(rt_scene::Alloc{d_items, item_bytes, offsetof(SceneDev, band_items)});
     s->scene_bytes += item_bytes;
+  }
+  s->dev.band_strip = d_strip;
+  if (d_strip) {
+    s->allocs.push_back(rt_scene::Alloc{d_strip, (n_items + 4) * 4, offsetof(SceneDev, band_strip)});
+    s->scene_bytes += (n_items + 4) * 4;
   }
   if (getenv("RT_AMD_DEBUG"))
     fprintf(stderr, "[rt_amd] band grid n=%d entries=%zu (%d-bit) built on the device\n", n, n_items, s->dev.band_items16 ? 16 : 32);
@@ -2917,7 +2976,7 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
   s->hint_valid = false;
   // ---- the cones' direction index follows their new matrices
   if (s->dev.band_grid_n > 0) {
-    for (size_t field : {RT_FIELD(band_start), RT_FIELD(band_items)})
+    for (size_t field : {RT_FIELD(band_start), RT_FIELD(band_items), RT_FIELD(band_strip)})
       for (size_t k = 0; k < s->allocs.size(); k++)
         if (s->allocs[k].field == field) {
           s->scene_bytes -= s->allocs[k].bytes;
@@ -3114,6 +3173,17 @@ extern "C" int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int
                        (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
                        (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
       for (int r = 0; r < 3; r++) d[r] = inv[r * 3] * ol[0] + inv[r * 3 + 1] * ol[1] + inv[r * 3 + 2] * ol[2];
+      if (next() & 1) {
+        // pushed across the band along the gradient of a, to anywhere between its two edges
+        const ConeBand& cb = bands[i];
+        double l = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        for (double& v : d) v /= l;
+        const double gr[3] = {2 * cb.q[0] * d[0] + cb.q[3] * d[1] + cb.q[4] * d[2], 2 * cb.q[1] * d[1] + cb.q[3] * d[0] + cb.q[5] * d[2],
+                              2 * cb.q[2] * d[2] + cb.q[4] * d[0] + cb.q[5] * d[1]};
+        const double g2 = gr[0] * gr[0] + gr[1] * gr[1] + gr[2] * gr[2], target = uni(-0.999, 0.999) * FEQ_EPSILON;
+        if (g2 > 1e-12)
+          for (int r = 0; r < 3; r++) d[r] += target / g2 * gr[r];
+      }
     } else {
       for (double& v : d) v = uni(-1, 1);
     }
@@ -3126,16 +3196,18 @@ extern "C" int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int
     m = xx >= (m == 2 ? zz : yy) ? 0 : m;
     const double dm = d[m], da = d[(m + 1) % 3], dc = d[(m + 2) % 3];
     const float inv = 1.0f / (float)dm, half_n = 0.5f * (float)n;
-    int iu = (int)floorf(((float)da * inv + 1.0f) * half_n), iv = (int)floorf(((float)dc * inv + 1.0f) * half_n);
-    iu = iu < 0 ? 0 : (iu >= n ? n - 1 : iu);
-    iv = iv < 0 ? 0 : (iv >= n ? n - 1 : iv);
+    int iu, iv;
+    float ls, lt;  // the cell and the local coordinates as the traversal computes them
+    band_strip_coords(((float)da * inv + 1.0f) * half_n, ((float)dc * inv + 1.0f) * half_n, n, iu, iv, ls, lt);
     const uint32_t cell = ((uint32_t)m * n + iv) * n + iu;
     for (int i = 0; i < n_bands; i++) {
       const ConeBand& cb = bands[i];
       double a = cb.q[0] * xx + cb.q[1] * yy + cb.q[2] * zz + cb.q[3] * xy + cb.q[4] * xz + cb.q[5] * yz;
       if (!(fabs(a) < FEQ_EPSILON * (1.0 + 1e-6) + cb.slack * dd)) continue;
-      bool found = std::binary_search(grid.items.begin() + grid.start[cell], grid.items.begin() + grid.start[cell + 1], (uint32_t)i);
-      if (!found) missing++;
+      auto at = std::lower_bound(grid.items.begin() + grid.start[cell], grid.items.begin() + grid.start[cell + 1], (uint32_t)i);
+      bool found = at != grid.items.begin() + grid.start[cell + 1] && *at == (uint32_t)i;
+      // listed in the cell, and the entry's strip holds the direction
+      if (!found || !band_strip_passes(grid.strip[(size_t)(at - grid.items.begin())], ls, lt)) missing++;
     }
   }
   return missing;

@@ -189,6 +189,7 @@ struct SceneDev {
   const QuadPrim* band_prims;
   const uint32_t* band_start;  // direction grid over bands (band_grid.h), null when band_grid_n == 0
   const uint32_t* band_items;  // the cells' entries: 32-bit band indices, or 16-bit ones when band_items16 is set
+  const uint32_t* band_strip;  // per entry: the strip of the cell the band lies in (band_grid_test.h), padded by four words
   const CsgRoot* csg_roots;
   const CsgNode* csg_nodes;
   const CsgLeaf* csg_leaves;
@@ -210,6 +211,10 @@ struct SceneDev {
   int32_t n_inline_planes;
   int32_t band_items16;  // 1: band_items holds uint16_t entries (scenes of fewer than 65536 bounded cones)
   int32_t csg_hits;      // entries of the per-ray CSG hit list (CSG_MIN_HITS .. CSG_MAX_HITS)
+#ifdef RT_DIAG_NO_BANDS
+  int32_t band_diag_passes;  // timing builds only: how many passes of the cone direction index run (0..3)
+  int32_t band_diag_pad;
+#endif
   InlinePlane inline_planes[MAX_INLINE_PLANES];
   double light_intensity[3];
   double light_position[3];
