@@ -2004,6 +2004,33 @@ bool leaf_box(const rt_leaf& L, const rt_xform& X, const rt_triangle* tri, doubl
     }
     default: return false;  // plane
   }
+  static const bool corner_boxes = getenv("RT_AMD_CORNER_BOXES") != nullptr;  // the looser boxes, for comparison
+  if (L.type != RT_CUBE && !corner_boxes) {
+    // Round shapes get their own extent along each world axis instead of the box of their object-space
+    // box's corners (up to sqrt(3) wider per axis under a rotation).  A sphere reaches
+    // sqrt(f_i0^2 + f_i1^2 + f_i2^2) from its centre along axis i.  A cylinder or cone lies in the hull of
+    // its two end discs (a cone's lines pass through the apex from one rim to the other), and a disc of
+    // radius r at height y reaches r sqrt(f_i0^2 + f_i2^2) from its centre f_i1 y + f_i3.
+    const bool sphere = L.type == RT_SPHERE;
+    const double ry0 = L.type == RT_CONE ? fabs(y0) : 1.0, ry1 = L.type == RT_CONE ? fabs(y1) : 1.0;
+    for (int a = 0; a < 3; a++) {
+      const double fx = f[a * 4 + 0], fy = f[a * 4 + 1], fz = f[a * 4 + 2], c = f[a * 4 + 3];
+      if (sphere) {
+        const double h = sqrt(fx * fx + fy * fy + fz * fz);
+        lo[a] = c - h;
+        hi[a] = c + h;
+      } else {
+        const double rho = sqrt(fx * fx + fz * fz);
+        lo[a] = c + fmin(fy * y0 - ry0 * rho, fy * y1 - ry1 * rho);
+        hi[a] = c + fmax(fy * y0 + ry0 * rho, fy * y1 + ry1 * rho);
+      }
+      // the same pad as box_of_points, and the rounding of the extent itself
+      const double pad = 2e-7 * (fabs(lo[a]) + fabs(hi[a]) + (hi[a] - lo[a])) + 1e-9;
+      lo[a] -= pad;
+      hi[a] += pad;
+    }
+    return true;
+  }
   double pts[8][3];
   for (int k = 0; k < 8; k++) {
     pts[k][0] = (k & 1) ? x1 : x0;
