@@ -947,6 +947,8 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     }
     const uint32_t first = cur & MAX_RUN_FIRST, count = ((cur >> 27) & 7u) + 1u;
     if (kind == KIND_TRI) {
+      int32_t local_of = -1;  // the transform `local` was made with: the triangles of a mesh share one
+      Ray local = ray;
       for (uint32_t i = 0; i < count; i++) {
         const TriIsect& tr = S.tris[first + i];
         if (COUNT) cnt.tri_tests++;
@@ -954,7 +956,10 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
         double t, u, v;
         bool hit;
         if (tr.xform >= 0) {
-          Ray local = tri_ray<Stack::WITH_CSG>(S, tr, ray);
+          if (tr.xform != local_of) {  // the same ray, the same matrix: the same object-space ray, made once
+            local = tri_ray<Stack::WITH_CSG>(S, tr, ray);
+            local_of = tr.xform;
+          }
           hit = intersect_triangle(tr, local, t, u, v);
         } else {
           hit = intersect_triangle(tr, ray, t, u, v);
