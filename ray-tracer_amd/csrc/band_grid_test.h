@@ -59,7 +59,7 @@ RT_HD bool band_cell_passes(const FacePoly& p, double thr, int level_n, int iu, 
 // A ray tests the word of every entry of its cell (one multiply-add and a compare) and only looks up
 // the bands whose strip it lies in: a few per cent of the entries.
 //   bits 31..20 g0, 19..9 m, 8..1 width code, 0: 1 when a = t.
-constexpr uint32_t BAND_STRIP_ALWAYS = 0xFFu;  // width code: every direction of the cell passes
+constexpr uint32_t BAND_STRIP_ALWAYS = 0xFFu;  // width code: every direction of the cell passes (a width of 31)
 
 // Width code c < 255 stands for 2^(c / 16 - 11) (1 + (c % 16) / 16): the f32 with bit pattern
 // (c << 19) + (116 << 23).
@@ -128,15 +128,16 @@ RT_HD void band_strip_coords(float x, float y, int n, int& iu, int& iv, float& s
   s = 2.0f * (x - (float)iu) - 1.0f;
   t = 2.0f * (y - (float)iv) - 1.0f;
 }
-RT_HD bool band_strip_passes(uint32_t word, float s, float t) {
-  const uint32_t code = (word >> 1) & 0xFFu;
-  const float g0 = (float)((int32_t)word >> 20) * (1.0f / 512.0f);
-  const float m = (float)((int32_t)(word << 12) >> 21) * (1.0f / 1024.0f);
-  const uint32_t wbits = (code << 19) + (116u << 23);
+// s1024, t1024: the local coordinates times 1024 (the unit of m's steps; g0's steps are two of them).
+// Width code 255 needs no case of its own: its bit pattern is a width of 31, above any |g0 + a + m b|.
+RT_HD bool band_strip_passes(uint32_t word, float s, float t, float s1024, float t1024) {
+  const float q0 = (float)((int32_t)word >> 20), qm = (float)((int32_t)(word << 12) >> 21);
+  const uint32_t wbits = (((word >> 1) & 0xFFu) << 19) + (126u << 23);  // the width times 1024
   float w;
   memcpy(&w, &wbits, 4);
-  const float a = (word & 1u) ? t : s, b = (word & 1u) ? s : t;
-  return code == BAND_STRIP_ALWAYS || fabsf((g0 + a) + m * b) <= w;
+  const bool t_major = (word & 1u) != 0u;
+  const float a = t_major ? t1024 : s1024, b = t_major ? s : t;
+  return fabsf((q0 * 2.0f + a) + qm * b) <= w;
 }
 
 }  // namespace rt

@@ -833,13 +833,19 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       uint32_t stop = end;
       if (band_passes == 0 && end != 0xFFFFFFFFu) stop = begin;  // the offsets are still fetched
       // all lanes stay in the loop until the longest list is through: flush() works on the whole wave
+      const float ls1024 = ls * 1024.0f, lt1024 = lt * 1024.0f;
+      auto words_at = [&](uint32_t k) {  // four strip words of the list, or padding behind its end (four words)
+        return *reinterpret_cast<const StripWords*>(S.band_strip + (k < stop ? k : stop));
+      };
+      StripWords next = words_at(begin);
       for (uint32_t k = begin; __any(k < stop); k += 4) {
-        const StripWords w = *reinterpret_cast<const StripWords*>(S.band_strip + (k < stop ? k : stop));  // padded by four words
+        const StripWords w = next;
+        next = words_at(k + 4);  // in flight while these four are looked at
         if (__any(st.sp + 4 > Stack::ENTRIES)) flush();
-        st.push_if(k, k < stop && band_strip_passes(w.x, ls, lt));  // room for four was made above
-        st.push_if(k + 1, k + 1 < stop && band_strip_passes(w.y, ls, lt));
-        st.push_if(k + 2, k + 2 < stop && band_strip_passes(w.z, ls, lt));
-        st.push_if(k + 3, k + 3 < stop && band_strip_passes(w.w, ls, lt));
+        st.push_if(k, k < stop && band_strip_passes(w.x, ls, lt, ls1024, lt1024));  // room for four was made above
+        st.push_if(k + 1, k + 1 < stop && band_strip_passes(w.y, ls, lt, ls1024, lt1024));
+        st.push_if(k + 2, k + 2 < stop && band_strip_passes(w.z, ls, lt, ls1024, lt1024));
+        st.push_if(k + 3, k + 3 < stop && band_strip_passes(w.w, ls, lt, ls1024, lt1024));
       }
       flush();
     } else {
@@ -3239,7 +3245,7 @@ extern "C" int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int
       auto at = std::lower_bound(grid.items.begin() + grid.start[cell], grid.items.begin() + grid.start[cell + 1], (uint32_t)i);
       bool found = at != grid.items.begin() + grid.start[cell + 1] && *at == (uint32_t)i;
       // listed in the cell, and the entry's strip holds the direction
-      if (!found || !band_strip_passes(grid.strip[(size_t)(at - grid.items.begin())], ls, lt)) missing++;
+      if (!found || !band_strip_passes(grid.strip[(size_t)(at - grid.items.begin())], ls, lt, ls * 1024.0f, lt * 1024.0f)) missing++;
     }
   }
   return missing;
