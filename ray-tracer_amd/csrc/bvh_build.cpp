@@ -22,7 +22,10 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 const int MAX_TRI_LEAF = env_int("RT_AMD_TRI_LEAF", 4);     // experiment knobs
-const int MAX_QUAD_LEAF = env_int("RT_AMD_QUAD_LEAF", 4);
+// One quadric per leaf: with boxes that fit the round shapes, a second primitive in a run is tested far
+// more often than it is hit (100k primitives: 4.2 tests per ray with runs of up to 4, 2.4 with single
+// primitives, 11 % less frame time for 8 % more node visits).
+const int MAX_QUAD_LEAF = env_int("RT_AMD_QUAD_LEAF", 1);
 constexpr int SOFT_DEPTH = 36;  // beyond this, split at the median so depth stays bounded
 
 const double INF = std::numeric_limits<double>::infinity();
