@@ -363,7 +363,7 @@ struct ClosestQuery {
     best_leaf = 0x7FFFFFFF;
     u = v = 0.0;
   }
-  DEV float hi_f() const { return __double2float_ru(best_t); }
+  DEV double hi_d() const { return best_t; }
   DEV bool done() const { return false; }
   DEV void offer(double t, int leaf, double uu, double vv) {
     if (t >= 0.0 && isfinite(t) && (t < best_t || (t == best_t && leaf < best_leaf))) {
@@ -384,7 +384,7 @@ struct ShadowQuery {
   static constexpr bool BEHIND = false;
   double distance;
   bool found;
-  DEV float hi_f() const { return __double2float_ru(distance); }
+  DEV double hi_d() const { return distance; }
   DEV bool done() const { return found; }
   DEV void leaf_ts(int, int n, const double* t) {
     for (int i = 0; i < n; i++)
@@ -413,7 +413,7 @@ struct ContainerQuery {
     other_key = -INFINITY;
     other_leaf = -1;
   }
-  DEV float hi_f() const { return INFINITY; }
+  DEV double hi_d() const { return INFINITY; }
   DEV bool done() const { return false; }
   DEV void container(int leaf, int count, double key) {
     if (!(count & 1)) return;
@@ -753,7 +753,8 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
   }
   if constexpr (Stack::WITH_CSG)
     for (int i = 0; i < S.n_csg_unbounded; i++) eval_csg<Query, Stack, Stack::THREADS>(S, S.csg_unbounded[i], ray, Q, st, true);
-  if (S.n_bands > 0) {
+  // The cones' parallel-ray branch (src/shape.rs:1089-1103): the cones whose band holds the ray's direction.
+  auto band_list = [&]() {
     const double dd = ray.d.x * ray.d.x + ray.d.y * ray.d.y + ray.d.z * ray.d.z;
     if (S.band_grid_n > 0 && dd >= 1.0 - 1e-6) {
       // cell of the direction on the sign-folded cube map; the grid was built for |d| >= 1 - 1e-6
@@ -860,11 +861,18 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
         }
       }
     }
-  }
+  };
+  // The order in which a query meets the shapes does not change its answer; the bands come first because
+  // their hits shorten the walk.  (A shadow query that walks the hierarchy first and looks the bands up
+  // only when it found nothing was measured: correct, but the shadow ray of a hit far out on a cone's
+  // extension runs back along that cone, and the band list ends it at once.)
+  if (S.n_bands > 0) band_list();
+  auto hierarchy = [&]() {
   if (S.root == REF_NONE || Q.done()) return;
-  const RayBox rb = make_raybox(ray, Query::BEHIND);
-  float qhi = Q.hi_f();
   const char* nodes = reinterpret_cast<const char*>(S.nodes);
+  const RayBox rb = make_raybox(ray, Query::BEHIND);
+  auto hi_f = [&]() { return __double2float_ru(Q.hi_d()); };  // the query's far bound, rounded up
+  float qhi = hi_f();
   st.clear();
   // rays without a near-zero direction component read the child references in which skippable
   // gates are already replaced by their subtrees
@@ -935,7 +943,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       if (g.csg) {
         if constexpr (Stack::WITH_CSG) eval_csg<Query, Stack, Stack::THREADS>(S, g.csg - 1u, ray, Q, st, false);
         if (Q.done()) break;
-        qhi = Q.hi_f();
+        qhi = hi_f();
         cur = st.pop_or_none();
         RT_TSTAMP(cnt, 3);
         continue;
@@ -982,9 +990,11 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       RT_TSTAMP(cnt, 3);
     }
     if (Q.done()) return;
-    qhi = Q.hi_f();
+    qhi = hi_f();
     cur = st.pop_or_none();
   }
+  };
+  hierarchy();
 }
 
 // ---------------------------------------------------------------------------

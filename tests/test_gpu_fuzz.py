@@ -149,7 +149,7 @@ def compare(out, stats, want, label):
 
 
 # RT_FUZZ_SEEDS, RT_FUZZ_CROWDS, RT_FUZZ_MESHES widen the sweeps (1500 / 80 / 400 seeds were run once: all equal)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_SEEDS", "60"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_SEEDS", "120"))))
 def test_random_scene_matches_oracle(pkg, root, seed):
     text = random_scene(seed)
     cpu = orc.OracleScene(text, base_dir=root)
@@ -188,7 +188,7 @@ def crowd_scene(seed, width=64, height=48):
         "shapes": shapes})
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_CROWDS", "8"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_CROWDS", "24"))))
 def test_random_crowd_matches_oracle(pkg, root, seed):
     text = crowd_scene(seed)
     gpu = pkg.Scene(text, base_dir=root, device=0)
