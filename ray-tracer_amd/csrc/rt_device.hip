@@ -528,7 +528,12 @@ struct RayBox {
   bool tiny;             // some |direction| component is below FEQ_EPSILON
 };
 
-DEV RayBox make_raybox(const Ray& r, bool reversed) {
+// Rounding of the reference's quadratic for round shapes, relative to |object-space origin|^2 (derived at
+// round_shape_noise() below), with a factor of four in hand.
+constexpr double ROUND_NOISE = 4.0 * 6.6e-16;
+
+// widen: a distance (world units) by which every box is to be taken larger for this ray, see round_shape_noise().
+DEV RayBox make_raybox(const Ray& r, bool reversed, float widen = 0.0f) {
   RayBox b;
   const double o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
   b.tiny = false;
@@ -544,7 +549,7 @@ DEV RayBox make_raybox(const Ray& r, bool reversed) {
     // scaled values and of the box test's multiply-add, the slack of 1e-6 |oinv| the second.
     const float inv = __builtin_amdgcn_rcpf(dirf);
     const float oinv = (float)o[a] * inv;
-    const float slack = fabsf(oinv) * 1e-6f + 1e-30f;
+    const float slack = fabsf(oinv) * 1e-6f + 1e-30f + widen * fabsf(inv) * (1.0f + 1e-6f);
     const float lo_s = 1.0f - 1.5e-6f, hi_s = 1.0f + 1.5e-6f;
     b.inv_n[a] = inv * lo_s;
     b.inv_f[a] = inv * hi_s;
@@ -870,7 +875,19 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
   auto hierarchy = [&]() {
   if (S.root == REF_NONE || Q.done()) return;
   const char* nodes = reinterpret_cast<const char*>(S.nodes);
-  const RayBox rb = make_raybox(ray, Query::BEHIND);
+  // The reference finds the roots of a round shape in object space, where b^2 - 4ac cancels for a far
+  // origin: with |origin|^2 = 1e14 a unit sphere's silhouette moves by a hundredth of its radius, and the
+  // reference's hits then lie outside the shape's box.  The boxes are taken larger by that much for this
+  // ray (nothing measurable for a ray that starts within 1e5 units of the scene).
+  float widen = 0.0f;
+  if (S.box_noise[0] > 0.0 || S.box_noise[1] > 0.0) {
+    const double q = 2.0 * (ray.o.x * ray.o.x + ray.o.y * ray.o.y + ray.o.z * ray.o.z + S.box_noise[2]);
+    if (q > 1e9) {  // within 2e4 units the rounding stays below the boxes' own pads on every scene tested
+      const double w = 0.5 * ROUND_NOISE * q * S.box_noise[0] + sqrt(ROUND_NOISE * q) * S.box_noise[1];
+      widen = w < 1e30 ? __double2float_ru(w) : 1e30f;  // NaN origins: the box tests see NaN either way
+    }
+  }
+  const RayBox rb = make_raybox(ray, Query::BEHIND, widen);
   auto hi_f = [&]() { return __double2float_ru(Q.hi_d()); };  // the query's far bound, rounded up
   float qhi = hi_f();
   st.clear();
@@ -1986,6 +2003,40 @@ void box_of_points(const double* fwd, const double (*pts)[3], int n, double lo[3
   }
 }
 
+// Rounding of the reference's quadratic (src/shape.rs:848-865, 987-1010, 1077-1112) for a ray whose
+// object-space origin o is far from the shape: b = 2 o.d, c = o.o - 1 and b^2 - 4ac each carry a few
+// relative roundings of |o|^2 |d|^2, about 24 * 1.1e-16 |o|^2 |d|^2 in the discriminant, which is
+// 4 |d|^2 (1 - p^2) for a line at distance p from the centre (axis): the reference reports hits up to
+// p^2 <= 1 + 6.6e-16 |o|^2.  ROUND_NOISE is that with a factor of four in hand.  For a shape with
+// object -> world matrix F and world -> object matrix M, |o| <= |M| (|origin| + |centre|) and a distance
+// in object space is at most |F| times as long in world space, so the silhouette moves by at most
+//   sphere, cylinder (radius 1):  |F| (sqrt(1 + x) - 1) <= |F| x / 2,   x = ROUND_NOISE |M|^2 q,
+//   cone (radius |y|, down to 0): |F| sqrt(x),
+// with q = 2 (|origin|^2 + |centre|^2) and Frobenius norms.  round_shape_noise() takes the largest
+// |F| |M|^2, |F| |M| and |centre|^2 over the scene's round shapes; the traversal widens its box tests by
+// the two terms for every ray (rt_types.h: SceneDev::box_noise).
+void round_shape_noise(const rt_scene_desc* d, double out[3]) {
+  out[0] = out[1] = out[2] = 0.0;
+  for (int32_t i = 0; i < d->n_leaves; i++) {
+    const rt_leaf& L = d->leaves[i];
+    if (L.type != RT_SPHERE && L.type != RT_CYLINDER && L.type != RT_CONE) continue;
+    const rt_xform& X = d->xforms[L.xform];
+    double f2 = 0, m2 = 0, c2 = 0;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) {
+        f2 += X.fwd[r * 4 + c] * X.fwd[r * 4 + c];
+        m2 += X.ray_inv[r * 4 + c] * X.ray_inv[r * 4 + c];
+      }
+      c2 += X.fwd[r * 4 + 3] * X.fwd[r * 4 + 3];
+    }
+    if (!(f2 < 1e300) || !(m2 < 1e300) || !(c2 < 1e300)) continue;  // degenerate matrices: such shapes have no box
+    const double f = sqrt(f2), m = sqrt(m2);
+    if (L.type == RT_CONE) out[1] = fmax(out[1], f * m);
+    else out[0] = fmax(out[0], f * m2);
+    out[2] = fmax(out[2], c2);
+  }
+}
+
 // World-space box of a leaf, or false when it has to be tested for every ray.
 bool leaf_box(const rt_leaf& L, const rt_xform& X, const rt_triangle* tri, double lo[3], double hi[3]) {
   const double* f = X.fwd;
@@ -2773,6 +2824,12 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
     s->dev.light_intensity[a] = d->light.intensity[a];
     s->dev.light_position[a] = d->light.position[a];
   }
+  round_shape_noise(d, s->dev.box_noise);
+  // Not in scenes with bounded cones: their parallel-ray branch (the band list) puts hits up to 1e8 units
+  // out on the cones' extensions, and a ray that starts there would, widened, meet every box of the scene
+  // one after the other in a single lane (measured: 12 -> 200 ms per frame with 25 000 cones, for rays
+  // whose reference results are rounding noise).  Far cameras and lights are the case this is for.
+  if (s->dev.n_bands > 0) s->dev.box_noise[0] = s->dev.box_noise[1] = 0.0;
 
   return RT_OK;
 }
@@ -3020,6 +3077,12 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
     s->dev.light_intensity[a] = d->light.intensity[a];
     s->dev.light_position[a] = d->light.position[a];
   }
+  round_shape_noise(d, s->dev.box_noise);
+  // Not in scenes with bounded cones: their parallel-ray branch (the band list) puts hits up to 1e8 units
+  // out on the cones' extensions, and a ray that starts there would, widened, meet every box of the scene
+  // one after the other in a single lane (measured: 12 -> 200 ms per frame with 25 000 cones, for rays
+  // whose reference results are rounding noise).  Far cameras and lights are the case this is for.
+  if (s->dev.n_bands > 0) s->dev.box_noise[0] = s->dev.box_noise[1] = 0.0;
   s->max_children = sh.max_children;
   s->hint_valid = false;
   // ---- the cones' direction index follows their new matrices

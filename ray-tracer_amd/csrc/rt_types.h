@@ -215,6 +215,9 @@ struct SceneDev {
   int32_t band_diag_passes;  // timing builds only: how many passes of the cone direction index run (0..3)
   int32_t band_diag_pad;
 #endif
+  // How far outside their exact shape the reference can report hits of round shapes for a ray from a
+  // far origin (make_raybox): [0] sphere / cylinder term, [1] cone term, [2] largest |centre|^2 of a round shape.
+  double box_noise[3];
   InlinePlane inline_planes[MAX_INLINE_PLANES];
   double light_intensity[3];
   double light_position[3];
