@@ -63,13 +63,6 @@ constexpr uint32_t BAND_STRIP_ALWAYS = 0xFFu;  // width code: every direction of
 
 // Width code c < 255 stands for 2^(c / 16 - 11) (1 + (c % 16) / 16): the f32 with bit pattern
 // (c << 19) + (116 << 23).
-RT_HD double band_strip_width(uint32_t code) {
-  double v = 1.0 + (double)(code & 15u) / 16.0;
-  int e = (int)(code >> 4) - 11;
-  for (; e > 0; e--) v *= 2.0;
-  for (; e < 0; e++) v *= 0.5;
-  return v;
-}
 RT_HD uint32_t band_strip_width_code(double w) {  // the smallest code whose width is >= w
   if (!(w > 0.00048828125)) return 0u;            // 2^-11
   uint32_t e = 0;
