@@ -4,12 +4,13 @@
 # default bench line, counters and frame times per configuration, and for the 100k-primitive field the cone
 # index's resolution table, its pass-by-pass timing (diagnostic build) and the phase shares with the band hits
 # used and dropped.  Needs `make -C ray-tracer_amd all diag probes lib/librt_host_nobands.so lib/librt_host_stamps.so`.
-# Results under gpurun_out/r02g/.
+# usage: tools/profile_round.sh [tag]      results under gpurun_out/<tag>/
 set -o pipefail
-bash tools/gpu_round.sh r02g || exit 1
-O=gpurun_out/r02g
+tag=${1:-profile}
+bash tools/gpu_round.sh $tag || exit 1
+O=gpurun_out/$tag
 timeout -k 10 300 python -u bench.py > $O/bench_final_tree.json 2> $O/bench_final_tree.err || exit 1
-bash tools/pmc_configs.sh r02g teapot glass heightfield primitives > $O/pmc_configs.log 2>&1 || { tail -20 $O/pmc_configs.log; exit 1; }
+bash tools/pmc_configs.sh $tag teapot glass heightfield primitives > $O/pmc_configs.log 2>&1 || { tail -20 $O/pmc_configs.log; exit 1; }
 timeout -k 10 600 python -u tools/bench_configs.py --counters > $O/configs.jsonl 2>>$O/err.log || exit 1
 : > $O/primitives_band_grid_resolution.jsonl
 for n in 512 1024 2048 4096; do
