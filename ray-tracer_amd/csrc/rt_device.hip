@@ -446,10 +446,11 @@ struct ContainerQuery {
 // Per-lane stack in LDS: entry e of thread t lives at stack[e * BLOCK + t], so
 // the 64 lanes of a wave hit 64 consecutive banks.
 #ifndef RT_PRIVATE_STACK
-template <int STACK, int BLOCK, bool CSG = false, bool UNIFORM = false>
+template <int STACK, int BLOCK, bool CSG = false, bool UNIFORM = false, bool TRIPF = false>
 struct LdsStack {
   static constexpr bool WITH_CSG = CSG;  // the kernels built for scenes with CSG operators carry eval_csg
   static constexpr bool UNIFORM_NODES = UNIFORM;  // ... and those for large hierarchies the scalar node path
+  static constexpr bool TRI_PREFETCH = TRIPF;  // ... and those for large meshes fetch a run's next triangle early
   static constexpr int THREADS = BLOCK;
   static constexpr int ENTRIES = STACK;
   uint32_t* base;
@@ -480,10 +481,11 @@ struct LdsStack {
 #define RT_STACK_LDS(n) (n)
 #else
 // Experiment: per-lane stack in private (scratch) memory instead of LDS.
-template <int STACK, int BLOCK, bool CSG = false, bool UNIFORM = false>
+template <int STACK, int BLOCK, bool CSG = false, bool UNIFORM = false, bool TRIPF = false>
 struct LdsStack {
   static constexpr bool WITH_CSG = CSG;
   static constexpr bool UNIFORM_NODES = UNIFORM;
+  static constexpr bool TRI_PREFETCH = TRIPF;
   static constexpr int THREADS = BLOCK;
   static constexpr int ENTRIES = STACK;
   uint32_t slot[STACK];
@@ -980,8 +982,16 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
     if (kind == KIND_TRI) {
       int32_t local_of = -1;  // the transform `local` was made with: the triangles of a mesh share one
       Ray local = ray;
+      // Kernels for large meshes hold the next record of the run in registers while this one is tested.
+      TriIsect ahead;
+      if constexpr (Stack::TRI_PREFETCH) ahead = S.tris[first];
       for (uint32_t i = 0; i < count; i++) {
-        const TriIsect& tr = S.tris[first + i];
+        TriIsect held;
+        if constexpr (Stack::TRI_PREFETCH) {
+          held = ahead;
+          if (i + 1 < count) ahead = S.tris[first + i + 1];
+        }
+        const TriIsect& tr = Stack::TRI_PREFETCH ? held : S.tris[first + i];
         if (COUNT) cnt.tri_tests++;
         RT_WAVE_ITER(cnt, 1);
         double t, u, v;
@@ -1337,13 +1347,13 @@ DEV void write_pixel(const ImageOut& img, uint32_t hsize, uint32_t x, uint32_t y
 #ifndef RT_SHADOW_ALWAYS
 #define RT_SHADOW_ALWAYS 0  // 1: traverse every shadow query, also those whose answer cannot reach the colour (A/B builds)
 #endif
-template <int STACK, bool COUNT, int MODE, bool CSG, bool UNIFORM>
+template <int STACK, bool COUNT, int MODE, bool CSG, bool UNIFORM, bool TRIPF = false>
 __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES_SPAWN)
     k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_segcap, int remaining,
                  uint32_t* next_counts, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
                  uint32_t tiles_x, ImageOut img, const uint32_t* queue_counts, uint32_t segcap) {
   __shared__ uint32_t lds[RT_STACK_LDS(STACK * BLOCK)];
-  LdsStack<STACK, BLOCK, CSG, UNIFORM> st;
+  LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF> st;
   extern __shared__ uint32_t csg_lds[];  // SceneDev::csg_hits * 3 * BLOCK words when the scene has CSG operators, else nothing
   st.init(lds, CSG ? csg_lds : nullptr);
 #ifdef RT_STAMPS
@@ -1394,7 +1404,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
   ClosestQuery Q;
   Q.init();
   RT_STAMP(0);  // ray generation
-  if (active) traverse<ClosestQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM>, COUNT>(S, ray, Q, st, ct);
+  if (active) traverse<ClosestQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, ray, Q, st, ct);
   RT_STAMP(1);  // closest-hit traversal
   const bool hit = active && Q.best_leaf != 0x7FFFFFFF;
   const int leaf = hit ? Q.best_leaf : -1;
@@ -1463,7 +1473,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
       if (m.flags & 8) {  // n1 / n2 are consumed: refraction or Schlick (src/intersect.rs:191-234)
         ContainerQuery C;
         C.init(leaf);
-        traverse<ContainerQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM>, COUNT>(S, ray, C, st, ct);
+        traverse<ContainerQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, ray, C, st, ct);
         double ri_hit = m.refractive_index;
         double ri_other = C.other_leaf >= 0 ? S.materials[S.leaves[C.other_leaf].material].refractive_index : 1.0;
         if (C.hit_inside) {
@@ -1568,7 +1578,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 ? RT_MIN_WAVES : RT_MIN_WAVES
                          __double_as_longlong(ag) != __double_as_longlong(lg) ||
                          __double_as_longlong(ab) != __double_as_longlong(lb);
     if (RT_SHADOW_ALWAYS || decides)
-      traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM>, COUNT>(S, shadow_ray, SQ, st, cs);
+      traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, shadow_ray, SQ, st, cs);
     out_r = SQ.found ? ar : lr;
     out_g = SQ.found ? ag : lg;
     out_b = SQ.found ? ab : lb;
@@ -1900,6 +1910,7 @@ struct rt_scene {
   bool hint_valid = false;
   uint32_t holdoff = 0, holdoff_next = 1;  // frames to render exactly after a speculative frame did not fit
   bool uniform_nodes = false;  // large hierarchy: kernels with the scalar path for nodes a whole wave visits
+  bool tri_prefetch = false;   // large mesh: kernels that fetch the next triangle of a run while one is tested
   int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
   GenBuf gens[MAX_GENERATIONS + 1];
   uint32_t* d_counts = nullptr;           // [gen][QUEUE_SEGMENTS]: rays queued for the next generation, per segment
@@ -2818,6 +2829,13 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
   // +5 %), whose upper levels stay in L1 anyway.
   s->uniform_nodes = b.bvh.nodes.size() >= 8192;
   if (const char* e = getenv("RT_AMD_UNIFORM_NODES")) s->uniform_nodes = atoi(e) != 0;
+  // Measured: in a run of triangles, fetching the next record while one is tested takes a tenth off the
+  // frame of a 1M-triangle mesh (2.72 -> 2.44 ms at 4K: ten triangle tests per ray, records far beyond a
+  // CU's L1) and costs the 12k-triangle teapot 6 % (the twenty registers held across a test are spilled,
+  // and its one or two tests per ray find their records in L1).  Scenes that spawn rays keep the plain
+  // loop (their kernels spill more than they gain).
+  s->tri_prefetch = s->uniform_nodes && b.tri_src.size() * sizeof(TriIsect) >= (4u << 20);
+  if (const char* e = getenv("RT_AMD_TRI_PREFETCH")) s->tri_prefetch = atoi(e) != 0;
   s->dev.n_unbounded = (int32_t)b.unbounded.size();
   s->dev.n_leaves = d->n_leaves;
   for (int a = 0; a < 3; a++) {
@@ -3164,6 +3182,7 @@ extern "C" int rt_scene_clone(const rt_scene* src, int device, rt_scene** out) {
     s->stack_need = src->stack_need;
     s->has_csg = src->has_csg;
     s->uniform_nodes = src->uniform_nodes;
+    s->tri_prefetch = src->tri_prefetch;
     s->max_children = src->max_children;
     s->host = src->host;  // vectors copied; the refit's device arrays are made on the first update
     s->host.d_tri_box = s->host.d_quad_box = nullptr;
@@ -3430,14 +3449,14 @@ struct GenLaunch {
 
 inline unsigned csg_lds_bytes(const rt_scene* s) { return (unsigned)s->dev.csg_hits * 3u * BLOCK * (unsigned)sizeof(uint32_t); }
 
-template <int STACK, bool COUNT, bool CSG, bool UNIFORM = false>
+template <int STACK, bool COUNT, bool CSG, bool UNIFORM = false, bool TRIPF = false>
 void launch_generation_mode(rt_scene* s, int mode, const GenLaunch& a) {
   dim3 grid(blocks_for(a.n)), block(BLOCK);
   static const unsigned env_lds = getenv("RT_AMD_EXTRA_LDS") ? (unsigned)atoi(getenv("RT_AMD_EXTRA_LDS")) : 0u;
   const unsigned extra_lds = (CSG ? csg_lds_bytes(s) : 0u) + env_lds;
 #define RT_GEN_ARGS s->dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap
   switch (mode) {
-    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
+    case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG, UNIFORM, TRIPF>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
     case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
     default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
   }
@@ -3450,10 +3469,12 @@ void launch_generation(rt_scene* s, int mode, bool count, const GenLaunch& a) {
     else launch_generation_mode<64, false, true>(s, mode, a);
   } else if (pick_stack(s->stack_need) == STACK_SMALL) {
     if (count) launch_generation_mode<STACK_SMALL, true, false>(s, mode, a);
+    else if (s->uniform_nodes && s->tri_prefetch && mode == 0) launch_generation_mode<STACK_SMALL, false, false, true, true>(s, mode, a);
     else if (s->uniform_nodes) launch_generation_mode<STACK_SMALL, false, false, true>(s, mode, a);
     else launch_generation_mode<STACK_SMALL, false, false>(s, mode, a);
   } else {
     if (count) launch_generation_mode<64, true, false>(s, mode, a);
+    else if (s->uniform_nodes && s->tri_prefetch && mode == 0) launch_generation_mode<64, false, false, true, true>(s, mode, a);
     else if (s->uniform_nodes) launch_generation_mode<64, false, false, true>(s, mode, a);
     else launch_generation_mode<64, false, false>(s, mode, a);
   }

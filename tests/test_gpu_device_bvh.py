@@ -129,3 +129,37 @@ def test_a_device_built_scene_is_updated_in_place(pkg):
     with builder(False):
         fresh = pkg.Scene(json.dumps(scene), ROOT, device=0)
     same(moving.render(), fresh.render())
+
+
+class kernels:
+    """Chooses the kernel variants of the scenes created inside the block (read from the environment per scene)."""
+
+    def __init__(self, large):
+        v = "1" if large else "0"
+        self.env = {"RT_AMD_UNIFORM_NODES": v, "RT_AMD_TRI_PREFETCH": v}
+
+    __enter__ = builder.__enter__
+    __exit__ = builder.__exit__
+
+
+@pytest.mark.parametrize("name", ["teapot", "allprims", "heightfield"])
+def test_images_do_not_depend_on_the_kernel_variant(pkg, name, tmp_path):
+    """Large scenes get kernels that read wave-uniform nodes through the scalar cache and fetch the next
+    triangle of a run while one is tested: forced on small scenes, every image is the same bit for bit."""
+    size = None
+    if name == "allprims":
+        text = open(os.path.join(GOLDEN, name + ".json")).read()
+    elif name == "heightfield":
+        import make_golden
+        text = open(make_golden.synthetic_scene(name, str(tmp_path))).read()
+    else:
+        text = open(os.path.join(ROOT, "scenes", name + ".json")).read()
+        size = (320, 180)
+    out = []
+    for large in (False, True):
+        with kernels(large):
+            s = pkg.Scene(text, ROOT, device=0)
+        if size:
+            s.set_canvas(*size)
+        out.append(s.render())
+    same(out[0], out[1])
