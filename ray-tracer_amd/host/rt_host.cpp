@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <limits>
 #include <sstream>
 #include <chrono>
@@ -1020,32 +1021,89 @@ void Canvas::save(const std::string& path) const {
   of.write(text.get(), (std::streamsize)length);
 }
 
+namespace {
+
+// All workers leave together; reusable.
+class Rendezvous {
+ public:
+  explicit Rendezvous(size_t n) : n_(n) {}
+  void arrive_and_wait() {
+    std::unique_lock<std::mutex> lock(m_);
+    const size_t round = round_;
+    if (++here_ == n_) {
+      here_ = 0;
+      round_++;
+      cv_.notify_all();
+    } else {
+      cv_.wait(lock, [&] { return round_ != round; });
+    }
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  size_t n_, here_ = 0, round_ = 0;
+};
+
+void check_rt(int rc) {
+  if (rc != RT_OK) throw std::runtime_error(rt_last_error());
+}
+
+// Workers of a render: one per GPU, at most as many as asked for (`jobs` counts worker threads in the
+// reference; here one worker drives one GPU).  RT_AMD_REHEARSE_JOBS=1 keeps up to 16 workers on fewer GPUs,
+// dealt round-robin, so that the several-GPU path can be run on a machine with one.
+size_t workers_for(size_t jobs, int gpus) {
+  const char* e = getenv("RT_AMD_REHEARSE_JOBS");
+  if (e && atoi(e) != 0) return std::min<size_t>(jobs, 16);
+  return std::min(jobs, (size_t)gpus);
+}
+
+// One acceleration structure for all GPUs (src/parallel.rs:183-204 shares one World between its threads):
+// the first GPU builds the scene, the others receive device-to-device copies of it (rt_scene_clone), made
+// by their own worker threads before any of them renders; then worker k renders part k of `jobs` on GPU k
+// (k modulo `gpus` when workers_for() let a rehearsal have more workers than GPUs).
+void render_on_gpus(const rt_scene_desc& desc, size_t jobs, int gpus, const std::function<int(rt_scene*, size_t)>& render) {
+  rt_scene* first = nullptr;
+  check_rt(rt_scene_create(&desc, 0, &first));
+  std::vector<std::string> errors(jobs);
+  Rendezvous cloned(jobs);
+  auto worker = [&](size_t k) {
+    rt_scene* sc = first;
+    if (k > 0 && rt_scene_clone(first, (int)(k % (size_t)gpus), &sc) != RT_OK) {
+      errors[k] = rt_last_error();
+      sc = nullptr;
+    }
+    cloned.arrive_and_wait();  // the source scene is read by the copies: nobody renders with it before they are made
+    if (sc && render(sc, k) != RT_OK) errors[k] = rt_last_error();
+    if (k > 0) rt_scene_destroy(sc);
+  };
+  std::vector<std::thread> threads;
+  for (size_t k = 1; k < jobs; k++) threads.emplace_back(worker, k);
+  worker(0);
+  for (auto& t : threads) t.join();
+  rt_scene_destroy(first);
+  for (const std::string& e : errors)
+    if (!e.empty()) throw std::runtime_error(e);
+}
+
+}  // namespace
+
 Canvas render_canvas(const World& world, const Camera& camera, size_t jobs) {
   if (jobs == 0) throw Panic("assertion failed: size > 0");  // src/parallel.rs:94
   int have = rt_device_count();
   if (have < 0) throw std::runtime_error(rt_last_error());
   if (have == 0) throw std::runtime_error("no GPU visible");
-  if ((size_t)have < jobs) jobs = (size_t)have;
+  jobs = workers_for(jobs, have);
   FlatWorld flat = flatten(world);
   rt_scene_desc desc = flat.desc();
   rt_camera cam = camera.describe();
   Canvas canvas(camera.hsize, camera.vsize);
   static_assert(sizeof(Color) == 3 * sizeof(double), "Color is three packed doubles");
   double* rgb64 = canvas.pixels.empty() ? nullptr : &canvas.pixels[0].r;
-  std::vector<std::string> errors(jobs);
-  auto worker = [&](size_t k) {  // every GPU writes its bands of 32 rows straight into the canvas
-    rt_scene* sc = nullptr;
-    if (rt_scene_create(&desc, (int)k, &sc) != RT_OK ||
-        rt_render_host(sc, &cam, (int)k, (int)jobs, RT_FLAG_BANDS, nullptr, rgb64, nullptr, nullptr) != RT_OK)
-      errors[k] = rt_last_error();
-    rt_scene_destroy(sc);
-  };
-  std::vector<std::thread> threads;
-  for (size_t k = 1; k < jobs; k++) threads.emplace_back(worker, k);
-  worker(0);
-  for (auto& t : threads) t.join();
-  for (const std::string& e : errors)
-    if (!e.empty()) throw std::runtime_error(e);
+  // every GPU writes its bands of 32 rows straight into the canvas
+  render_on_gpus(desc, jobs, have, [&](rt_scene* sc, size_t k) {
+    return rt_render_host(sc, &cam, (int)k, (int)jobs, RT_FLAG_BANDS, nullptr, rgb64, nullptr, nullptr);
+  });
   return canvas;
 }
 
@@ -1061,7 +1119,7 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
   fflush(stdout);
   // `jobs` counts worker threads in the reference; here one worker drives one GPU, so a request for
   // more workers than GPUs uses every GPU there is
-  if ((size_t)have < jobs) jobs = (size_t)have;
+  jobs = workers_for(jobs, have);
   // RT_AMD_TIMINGS=1: where the wall time of one call goes, on stderr
   const bool timings = getenv("RT_AMD_TIMINGS") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1091,20 +1149,9 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
   lap("device start, frame memory", t);
   if (!frame.p) frame.p = (uint8_t*)malloc(std::max<size_t>(np * 3, 1));
   if (!frame.p) throw std::bad_alloc();
-  std::vector<std::string> errors(jobs);
-  auto worker = [&](size_t k) {
-    rt_scene* sc = nullptr;
-    if (rt_scene_create(&desc, (int)k, &sc) != RT_OK ||
-        rt_render_host(sc, &cam, (int)k, (int)jobs, RT_FLAG_BANDS, frame.p, nullptr, nullptr, nullptr) != RT_OK)
-      errors[k] = rt_last_error();
-    rt_scene_destroy(sc);
-  };
-  std::vector<std::thread> threads;
-  for (size_t k = 1; k < jobs; k++) threads.emplace_back(worker, k);
-  worker(0);
-  for (auto& t : threads) t.join();
-  for (const std::string& e : errors)
-    if (!e.empty()) throw std::runtime_error(e);
+  render_on_gpus(desc, jobs, have, [&](rt_scene* sc, size_t k) {
+    return rt_render_host(sc, &cam, (int)k, (int)jobs, RT_FLAG_BANDS, frame.p, nullptr, nullptr, nullptr);
+  });
   lap("scene upload, BVH, render", t);
   // Canvas::save (src/canvas.rs:47-94): the text is formatted on the first GPU (the frame goes up,
   // the file comes down), about ten times faster than this host's one-core writer at 4K
@@ -1128,36 +1175,6 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
 // ===========================================================================
 // FrameLoop: parallel_render's workers over many frames
 // ===========================================================================
-namespace {
-
-// All workers leave together; reusable.
-class Rendezvous {
- public:
-  explicit Rendezvous(size_t n) : n_(n) {}
-  void arrive_and_wait() {
-    std::unique_lock<std::mutex> lock(m_);
-    const size_t round = round_;
-    if (++here_ == n_) {
-      here_ = 0;
-      round_++;
-      cv_.notify_all();
-    } else {
-      cv_.wait(lock, [&] { return round_ != round; });
-    }
-  }
-
- private:
-  std::mutex m_;
-  std::condition_variable cv_;
-  size_t n_, here_ = 0, round_ = 0;
-};
-
-void check_rt(int rc) {
-  if (rc != RT_OK) throw std::runtime_error(rt_last_error());
-}
-
-}  // namespace
-
 FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth, const Share& share)
     : devices_(devices), depth_(depth) {
   if (devices.empty()) throw Panic("assertion failed: size > 0");  // src/parallel.rs:94

@@ -358,6 +358,14 @@ def test_parallel_render_writes_the_reference_ppm(pkg, root, tmp_path):
         a = np.array(got.split()[4:], dtype=int)
         b = np.array(ref.split()[4:], dtype=int)
         assert a.shape == b.shape and np.abs(a - b).max() <= 1 and (a != b).sum() <= 5
+    # three workers on this one GPU (a rehearsal of the several-GPU path): one build, two device-to-device
+    # copies of the scene, every worker its own bands of one frame
+    out3 = tmp_path / "c.ppm"
+    p3 = subprocess.run([cli, "-s", scene, "-o", str(out3), "-j", "3"], capture_output=True, text=True, timeout=120, cwd=root,
+                        env=dict(os.environ, RT_AMD_REHEARSE_JOBS="1"))
+    assert p3.returncode == 0, p3.stderr
+    assert "Rendering using 3 threads..." in p3.stdout
+    assert out3.read_bytes() == got
     bad = subprocess.run([cli, "-s", os.path.join(root, "absent.json"), "-o", str(out2)], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0
 
