@@ -155,7 +155,7 @@ def bench_single_process(args):
         sha, hbm_s = None, None
     else:
         host_s, host_stats = loop.run(PRIMING + args.warmup, args.steps, True)
-        frame = loop.host_frame((PRIMING + args.warmup + args.steps - 1) % DEPTH)
+        frame = loop.host_frame((PRIMING + args.warmup + args.steps - 1) % DEPTH).copy()
         sha = hashlib.sha256(frame.tobytes()).hexdigest()
         hbm_s = None if args.no_hbm_leg else loop.run(PRIMING + args.warmup, args.steps, False)[0]
     lone = sum_stats(loop.blocking_frames(10, False))
@@ -205,7 +205,17 @@ def bench_single_process(args):
         c1 = time.perf_counter()
         res1 = ref.render(jobs=1, xstep=4 * s, ystep=4 * s)
         cpu1_s = time.perf_counter() - c1
-        cpu_baseline = {"value": cpu_rays / cpu_s, "unit": "rays/s", "cores": cores, "kind": "port",
+        # the oracle's frame is there anyway: the last timed frame on the host is checked against it
+        checked = None
+        if sha is not None:
+            import numpy as np
+            got = np.asarray(frame).reshape(H, W, 3)[::s, ::s].astype(np.int16)
+            want = orc.quantise(res["rgb64"][::s, ::s]).astype(np.int16)
+            levels = np.abs(got - want).max(axis=2)
+            checked = {"pixels_compared": int(levels.size), "pixels_differing": int((levels > 0).sum()),
+                       "pixels_off_by_more_than_one_level": int((levels > 1).sum()),
+                       "note": "8-bit frame of the last timed step in host memory against ceil(clamp(255 c)) of the CPU baseline's frame"}
+        cpu_baseline = {"value": cpu_rays / cpu_s, "unit": "rays/s", "cores": cores, "kind": "port", "frame_check": checked,
                         "cores_from": source, "cpus_of_the_machine": os.cpu_count(),
                         "single_core_value": sum(res1["counts"]) / cpu1_s,
                         "sample": "C++ restatement of the reference algorithm (group box gate + linear scan of all %d "
