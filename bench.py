@@ -42,7 +42,12 @@ BYTES_PIXEL = 3
 RECORD_BYTES = 13 * 8 + 4 * 4  # one ray record of a generation buffer
 
 DEPTH = int(os.environ.get("RT_BENCH_DEPTH", "4"))  # frames in flight per GPU = host frames in the ring
-PRIMING = 64  # untimed frames before the warmup: first launches load code objects and grow runtime pools
+# Untimed frames before the warmup, as a stretch of their own that ends with every GPU idle.  A fresh process pays
+# about 11 ms once for its first launches (code objects, runtime pools), and a second part of that comes only after
+# some fifty to seventy frames of continuous work: with 64 priming frames it fell into the 20 timed frames of one
+# run in six (0.42 instead of 0.136 ms per frame; tools/probes/stall_probe.py).  Past the first hundred frames no
+# stretch of a process is slow again (600 stretches of 20 frames: 2.72 .. 2.99 ms).
+PRIMING = 256
 
 
 def host_cores():
@@ -150,14 +155,15 @@ def bench_single_process(args):
 
     # The timed region of the metric: frames on the host.  Then the same frames left in HBM, frames
     # rendered one at a time (lone launches), and one instrumented frame.
+    loop.run(0, PRIMING, not args.hbm_only)  # untimed
     if args.hbm_only:  # profiling aid: rocprofv3 turns the DMA copies into copy kernels that share the GPU with the render
-        host_s, host_stats = loop.run(PRIMING + args.warmup, args.steps, False)
+        host_s, host_stats = loop.run(args.warmup, args.steps, False)
         sha, hbm_s = None, None
     else:
-        host_s, host_stats = loop.run(PRIMING + args.warmup, args.steps, True)
-        frame = loop.host_frame((PRIMING + args.warmup + args.steps - 1) % DEPTH).copy()
+        host_s, host_stats = loop.run(args.warmup, args.steps, True)
+        frame = loop.host_frame((args.warmup + args.steps - 1) % DEPTH).copy()
         sha = hashlib.sha256(frame.tobytes()).hexdigest()
-        hbm_s = None if args.no_hbm_leg else loop.run(PRIMING + args.warmup, args.steps, False)[0]
+        hbm_s = None if args.no_hbm_leg else loop.run(args.warmup, args.steps, False)[0]
     lone = sum_stats(loop.blocking_frames(10, False))
     counted = sum_stats(loop.blocking_frames(1, True))
     piped = sum_stats(host_stats)
