@@ -351,8 +351,9 @@ int rt_is_shadowed(rt_scene* scene, uint64_t n, const double* points3, uint8_t* 
  * `device`, width * height * 3 bytes, row-major, finished - call rt_scene_wait first if it was
  * rendered with RT_FLAG_ASYNC) becomes the text of the reference's PPM file in out_dev (device memory,
  * capacity >= rt_ppm_max_bytes(width, height)): header, numbers, the reference's 70-column line
- * breaks, final newline, byte for byte.  *length receives the size of the file.  Blocking; uses a
- * temporary workspace of about 2.3 bytes per pixel.  The file then crosses PCIe once (rt_download
+ * breaks, final newline, byte for byte.  *length receives the size of the file.  Blocking; works in
+ * about 2.3 bytes per pixel: the GPU's fixed array of rt_ppm_encode_static when the frame fits it and no
+ * other call is using it (then nothing is allocated), else a workspace allocated for the call.  The file then crosses PCIe once (rt_download
  * or hipMemcpy) instead of being formatted from a host copy of the frame. */
 int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
                   uint64_t capacity, uint64_t* length);
@@ -365,8 +366,11 @@ int rt_ppm_encode_host(int device, const uint8_t* rgb8_host, uint64_t width, uin
  * result byte for byte, but the workspace is a fixed array in the library's device image (about 18.4 MB
  * on every GPU the library runs on, held until the process ends) instead of a hipMalloc per call, and the
  * call makes no allocation of its own.  Frames of more than rt_ppm_static_max_pixels() pixels (one
- * 3840x2160 frame) are refused with RT_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's array:
- * calls that overlap on one GPU race; calls on different GPUs do not. */
+ * 3840x2160 frame) are refused with RT_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's array, which
+ * keeps the last call's contents (nothing in it has to start at zero): calls that overlapped in it would race,
+ * so the library lets one call at a time into a GPU's array (a host-side lock per GPU: a second call on the
+ * same GPU waits for the first to return; rt_ppm_encode, which borrows the array when it is free, never
+ * waits and allocates instead).  Calls on different GPUs do not meet. */
 int rt_ppm_encode_static(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
                          uint64_t capacity, uint64_t* length);
 uint64_t rt_ppm_static_max_pixels(void);

@@ -391,22 +391,6 @@ done:
 
 }  // namespace
 
-extern "C" int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
-                             uint64_t capacity, uint64_t* length) {
-  int rc = ppm_check_arguments("rt_ppm_encode", rgb8_dev, width, height, out_dev, capacity, length);
-  if (rc != RT_OK) return rc;
-  char* ws = nullptr;
-  int previous = -1;
-  PPM_TRY(hipGetDevice(&previous));
-  PPM_TRY(hipSetDevice(device));
-  PPM_TRY(hipMalloc((void**)&ws, ppm_layout(width * height).bytes));
-  rc = ppm_run(ws, rgb8_dev, width, height, out_dev, length, nullptr);
-done:
-  if (ws) (void)hipFree(ws);
-  if (previous >= 0) (void)hipSetDevice(previous);
-  return rc;
-}
-
 // ---------------------------------------------------------------------------
 // The same encoder for callers that cannot allocate (code under HIP graph capture, serving loops that
 // forbid hipMalloc): the workspace is a fixed array in the library's device image, one copy per GPU.
@@ -437,7 +421,49 @@ int scratch_on_current_device(int device, char** out) {
   *out = g_scratch_ptr[device];
   return RT_OK;
 }
+
+// One call at a time works in a GPU's array: calls on one GPU take turns.
+std::mutex g_scratch_turn[PPM_MAX_DEVICES];
+
+// The encoder in the fixed workspace of `device` (current, frame within PPM_STATIC_MAX_PIXELS).  wait_for_turn:
+// block until the array is free; otherwise return at once with *ran = false when another call is using it.
+int ppm_run_in_scratch(int device, bool wait_for_turn, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
+                       uint64_t* length, bool* ran) {
+  *ran = false;
+  std::unique_lock<std::mutex> turn(g_scratch_turn[device], std::defer_lock);
+  if (wait_for_turn) turn.lock();
+  else if (!turn.try_lock()) return RT_OK;
+  char* ws = nullptr;
+  int rc = scratch_on_current_device(device, &ws);
+  if (rc != RT_OK) return rc;
+  *ran = true;
+  // nothing in the workspace has to start at zero: every word a kernel reads was written earlier in the same call
+  return ppm_run(ws, rgb8_dev, width, height, out_dev, length, nullptr);
+}
 }  // namespace
+
+// Frames up to one 3840x2160 work in the GPU's fixed array when no other call is using it (no hipMalloc / hipFree
+// per frame); larger frames, and calls that find the array taken, allocate their own workspace.
+extern "C" int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
+                             uint64_t capacity, uint64_t* length) {
+  int rc = ppm_check_arguments("rt_ppm_encode", rgb8_dev, width, height, out_dev, capacity, length);
+  if (rc != RT_OK) return rc;
+  char* ws = nullptr;
+  int previous = -1;
+  bool ran = false;
+  PPM_TRY(hipGetDevice(&previous));
+  PPM_TRY(hipSetDevice(device));
+  if (width * height <= PPM_STATIC_MAX_PIXELS && device >= 0 && device < PPM_MAX_DEVICES) {
+    rc = ppm_run_in_scratch(device, false, rgb8_dev, width, height, out_dev, length, &ran);
+    if (rc != RT_OK || ran) goto done;
+  }
+  PPM_TRY(hipMalloc((void**)&ws, ppm_layout(width * height).bytes));
+  rc = ppm_run(ws, rgb8_dev, width, height, out_dev, length, nullptr);
+done:
+  if (ws) (void)hipFree(ws);
+  if (previous >= 0) (void)hipSetDevice(previous);
+  return rc;
+}
 
 extern "C" uint64_t rt_ppm_static_max_pixels(void) { return PPM_STATIC_MAX_PIXELS; }
 
@@ -451,12 +477,11 @@ extern "C" int rt_ppm_encode_static(int device, const uint8_t* rgb8_dev, uint64_
   if (device < 0 || device >= PPM_MAX_DEVICES) return rt_fail_message(RT_ERR_INVALID, "rt_ppm_encode_static: device out of range");
   static_assert(ppm_layout(PPM_STATIC_MAX_PIXELS).bytes <= sizeof(scratch), "the fixed workspace holds the largest frame");
   int previous = -1;
-  char* ws = nullptr;
+  bool ran = false;
   PPM_TRY(hipGetDevice(&previous));
   PPM_TRY(hipSetDevice(device));
-  rc = scratch_on_current_device(device, &ws);
-  // nothing in the workspace has to start at zero: every word a kernel reads was written earlier in the same call
-  if (rc == RT_OK) rc = ppm_run(ws, rgb8_dev, width, height, out_dev, length, nullptr);
+  rc = ppm_run_in_scratch(device, true, rgb8_dev, width, height, out_dev, length, &ran);
+  (void)ran;
 done:
   if (previous >= 0) (void)hipSetDevice(previous);
   return rc;
