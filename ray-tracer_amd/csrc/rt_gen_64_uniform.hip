@@ -1,0 +1,8 @@
+// Instantiations of the generation kernel (rt_generation.h): one translation unit per group, so that
+// they compile side by side.
+#include "rt_generation.h"
+
+namespace rt {
+template void launch_generation_variant<64, false, false, true, false>(const SceneDev&, unsigned, int, const GenLaunch&);
+template void launch_generation_variant<64, false, false, true, true>(const SceneDev&, unsigned, int, const GenLaunch&);
+}  // namespace rt

@@ -1,0 +1,405 @@
+// Host side of a frame: the generation kernels launched one after the other (or all at once on the last
+// frame's queue lengths), the colours resolved back through the generations, asynchronous frames.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "rt_scene.h"
+
+using namespace rt;
+
+int rt::ensure_gen(rt_scene* s, int g, size_t cap) {
+  GenBuf& b = s->gens[g];
+  if (cap == 0) cap = 64;
+  if (b.capacity >= cap) return RT_OK;
+  if (b.slab) {
+    HIP_TRY(hipStreamSynchronize(main_stream(s)));
+    HIP_TRY(hipFree(b.slab));
+    b.slab = nullptr;
+    b.capacity = 0;
+  }
+  HIP_TRY(hipMalloc(&b.slab, gen_bytes(cap)));
+  b.capacity = cap;
+  carve(b);
+  return RT_OK;
+}
+
+namespace {
+
+// The kernel for this scene and generation: the instantiations live in rt_gen_*.hip.
+void launch_generation(rt_scene* s, int mode, bool count, const GenLaunch& a) {
+  static const unsigned env_lds = getenv("RT_AMD_EXTRA_LDS") ? (unsigned)atoi(getenv("RT_AMD_EXTRA_LDS")) : 0u;
+  const unsigned lds = (s->has_csg ? csg_lds_bytes(s) : 0u) + env_lds;
+  const bool small = pick_stack(s->stack_need) == STACK_SMALL;
+  const bool tripf = s->uniform_nodes && s->tri_prefetch && mode == 0;
+  if (s->has_csg) {  // scenes with CSG operators or transform chains: the general kernels (64-entry stack)
+    if (count) launch_generation_variant<64, true, true, false, false>(s->dev, lds, mode, a);
+    else launch_generation_variant<64, false, true, false, false>(s->dev, lds, mode, a);
+  } else if (small) {
+    if (count) launch_generation_variant<STACK_SMALL, true, false, false, false>(s->dev, lds, mode, a);
+    else if (tripf) launch_generation_variant<STACK_SMALL, false, false, true, true>(s->dev, lds, mode, a);
+    else if (s->uniform_nodes) launch_generation_variant<STACK_SMALL, false, false, true, false>(s->dev, lds, mode, a);
+    else launch_generation_variant<STACK_SMALL, false, false, false, false>(s->dev, lds, mode, a);
+  } else {
+    if (count) launch_generation_variant<64, true, false, false, false>(s->dev, lds, mode, a);
+    else if (tripf) launch_generation_variant<64, false, false, true, true>(s->dev, lds, mode, a);
+    else if (s->uniform_nodes) launch_generation_variant<64, false, false, true, false>(s->dev, lds, mode, a);
+    else launch_generation_variant<64, false, false, false, false>(s->dev, lds, mode, a);
+  }
+}
+
+}  // namespace
+
+CameraDev rt::camera_dev(const rt_camera* c) {
+  CameraDev cd;
+  cd.hsize = c->hsize;
+  cd.vsize = c->vsize;
+  cd.half_width = c->half_width;
+  cd.half_height = c->half_height;
+  cd.pixel_size = c->pixel_size;
+  copy3x4(cd.inv, c->inv);
+  return cd;
+}
+
+namespace rt {
+
+static void decode_stats(const unsigned long long* h, rt_stats* stats) {
+  unsigned long long sums[3] = {0, 0, 0};
+  for (int k = 0; k < 3; k++)
+    for (int j = 0; j < STAT_SLOTS; j++) sums[k] += h[STAT_RAYS + k * STAT_SLOTS + j];
+  stats->shadow = sums[0];
+  stats->reflect = sums[1];
+  stats->refract = sums[2];
+  stats->node_visits = h[0];
+  stats->tri_tests = h[1];
+  stats->quadric_tests = h[2];
+  stats->gate_tests = h[3];
+  stats->shadow_node_visits = h[4];
+  stats->shadow_tri_tests = h[5];
+  stats->shadow_quadric_tests = h[6];
+  stats->shadow_gate_tests = h[7];
+}
+
+// Waits for one asynchronous frame and adds its kernel time to the scene's running total.
+static int collect_frame(rt_scene* s, rt_scene::FrameSlot& f) {
+  if (!f.pending) return RT_OK;
+  HIP_TRY(hipEventSynchronize(f.end));
+  f.pending = false;
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, f.begin, f.end));
+  rt_stats& t = s->async_total;
+  t.primary += f.primary;
+  t.kernel_ms += ms;
+  t.kernel_launches += 1;
+  t.generations += 1;
+  return RT_OK;
+}
+
+// Waits for every asynchronous frame, then reads and clears the counters they added to.
+int collect_all(rt_scene* s) {
+  for (int k = 0; k < rt_scene::FRAME_SLOTS; k++) {
+    int rc = collect_frame(s, s->slots[(s->next_slot + k) % rt_scene::FRAME_SLOTS]);
+    if (rc) return rc;
+  }
+  if (!s->async_counters_dirty) return RT_OK;
+  HIP_TRY(hipMemcpy(s->h_async_stats, s->d_async_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(s->d_async_stats, 0, STAT_WORDS * sizeof(unsigned long long)));
+  s->async_counters_dirty = false;
+#ifdef RT_STAMPS
+  {
+    const unsigned long long* t = s->h_async_stats + STAT_RAYS + 3 * STAT_SLOTS;
+    double sum = 0;
+    for (int k = 0; k < 5; k++) sum += (double)t[k];
+    fprintf(stderr, "[rt_amd] wave clock shares: raygen %.3f closest %.3f shade %.3f shadow %.3f output %.3f (total %.3g ticks)\n",
+            t[0] / sum, t[1] / sum, t[2] / sum, t[3] / sum, t[4] / sum, sum);
+    fprintf(stderr, "[rt_amd]   closest: setup %.3f nodes %.3f tris %.3f quads/gates %.3f | shadow: setup %.3f nodes %.3f tris %.3f quads/gates %.3f\n",
+            t[8] / sum, t[9] / sum, t[10] / sum, t[11] / sum, t[16] / sum, t[17] / sum, t[18] / sum, t[19] / sum);
+    fprintf(stderr, "[rt_amd]   wave-level loop iterations: closest nodes %llu tris %llu quads %llu rounds %llu | shadow nodes %llu tris %llu quads %llu rounds %llu\n",
+            t[12], t[13], t[14], t[15], t[20], t[21], t[22], t[23]);
+  }
+#endif
+  rt_stats one{};
+  decode_stats(s->h_async_stats, &one);
+  rt_stats& t = s->async_total;
+  t.shadow += one.shadow; t.reflect += one.reflect; t.refract += one.refract;
+  t.node_visits += one.node_visits; t.tri_tests += one.tri_tests;
+  t.quadric_tests += one.quadric_tests; t.gate_tests += one.gate_tests;
+  t.shadow_node_visits += one.shadow_node_visits; t.shadow_tri_tests += one.shadow_tri_tests;
+  t.shadow_quadric_tests += one.shadow_quadric_tests; t.shadow_gate_tests += one.shadow_gate_tests;
+  return RT_OK;
+}
+
+// One camera frame of a scene that spawns no rays: a single kernel, nothing to read back, so the
+// frame is only enqueued.
+int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
+  rt_scene::FrameSlot& f = s->slots[s->next_slot];
+  int rc = collect_frame(s, f);  // the slot's previous frame, FRAME_SLOTS frames ago
+  if (rc) return rc;
+  // consecutive frames go to different streams: they do not depend on each other, and the tail of
+  // one kernel (few waves left) overlaps the head of the next
+  // a whole frame fills the GPU from two streams (a third only stretches every launch); a part of a frame does not
+  const unsigned lanes = in.tiles ? (unsigned)s->n_frame_streams : std::min(2u, (unsigned)s->n_frame_streams);
+  const unsigned lane = s->frame_seq++ % lanes;
+  hipStream_t stream = lane ? s->frame_stream[lane - 1] : main_stream(s);
+  if (lane) s->frame_stream_used[lane - 1] = true;
+  s->last_stream = stream;
+  s->next_slot = (s->next_slot + 1) % rt_scene::FRAME_SLOTS;
+  GenLaunch a;
+  a.cur = s->gens[0].view;
+  a.next = s->gens[1].view;
+  a.n = in.n0;
+  a.next_segcap = 0;
+  a.remaining = 0;
+  a.next_counts = s->d_counts;
+  a.cam = in.cam;
+  a.tiles = in.tiles;
+  a.tiles_x = in.tiles_x;
+  a.img = in.img;
+  a.stats = s->d_async_stats;
+  s->async_counters_dirty = true;
+  a.stream = stream;
+  HIP_TRY(hipEventRecord(f.begin, stream));
+  launch_generation(s, 0, (in.flags & RT_FLAG_COUNTERS) != 0, a);
+  HIP_TRY(hipEventRecord(f.end, stream));
+  HIP_TRY(hipGetLastError());
+  f.primary = primary;
+  f.pending = true;
+  return RT_OK;
+}
+
+// Record slots per queue segment that can never overflow: the waves of a generation of n rays are dealt
+// to the segments round-robin and a wave spawns at most 64 * max_children rays.
+static inline uint64_t safe_segcap(uint64_t n, uint32_t max_children) {
+  const uint64_t waves = (n + 63) / 64;
+  return (waves + QUEUE_SEGMENTS - 1) / QUEUE_SEGMENTS * 64 * max_children;
+}
+
+struct GenPlan {
+  uint32_t threads[MAX_GENERATIONS + 2] = {0};  // grid size of generation g (for g > 0 an upper bound when speculative)
+  uint32_t segcap[MAX_GENERATIONS + 2] = {0};   // record slots per queue segment of generation g (g > 0)
+};
+
+static void fill_launch(rt_scene* s, const PipelineIn& in, const GenPlan& plan, int g, int max_gen, GenLaunch& a) {
+  a.cur = s->gens[g].view;
+  a.next = s->gens[g + 1].view;
+  a.n = plan.threads[g];
+  a.next_segcap = g < max_gen ? plan.segcap[g + 1] : 0;
+  a.remaining = g < max_gen ? std::max(in.remaining0 - g, 0) : 0;
+  a.next_counts = s->d_counts + g * QUEUE_SEGMENTS;
+  a.cam = in.cam;
+  a.tiles = in.tiles;
+  a.tiles_x = in.tiles_x;
+  a.img = in.img;
+  a.stats = s->d_stats;
+  a.stream = main_stream(s);
+  a.queue_counts = g > 0 ? s->d_counts + (g - 1) * QUEUE_SEGMENTS : nullptr;
+  a.segcap = plan.segcap[g];
+}
+
+static void launch_resolve_generation(rt_scene* s, const GenPlan& plan, int g) {
+  launch_resolve(main_stream(s), s->gens[g].view, plan.threads[g], s->gens[g + 1].view,
+                 g > 0 ? s->d_counts + (g - 1) * QUEUE_SEGMENTS : (const uint32_t*)nullptr, plan.segcap[g]);
+}
+
+// Colours flow back from the last generation to the first; a camera frame ends in its pixels.
+static void launch_resolves(rt_scene* s, const PipelineIn& in, const GenPlan& plan, int last) {
+  for (int g = last - 1; g >= (in.camera ? 1 : 0); g--) launch_resolve_generation(s, plan, g);
+  if (in.camera && last > 0)
+    launch_resolve_pixels(main_stream(s), s->gens[0].view, in.n0, s->gens[1].view, in.cam, in.tiles, in.tiles_x, in.img);
+}
+
+// The frame launched at once on twice the queue lengths of the frame before (scene->hint; unused room
+// costs waves that exit at once):
+// no host round trip between the generations; the kernels find their rays through the segment counters
+// on the device.  The counters come back in one copy at the end.  *fits = false when a segment
+// received more rays than it had room for: the frame's output is then unusable.
+// Sizes the generations from the hints and makes room for them; returns the last generation to launch.
+static int plan_speculative(rt_scene* s, const PipelineIn& in, int max_gen, GenPlan& plan, int* last_out) {
+  plan.threads[0] = in.n0;
+  int last = 0;
+  for (int g = 1; g <= max_gen && s->hint[g] > 0; g++) {
+    const uint64_t safe = safe_segcap(plan.threads[g - 1], s->max_children);
+    const uint64_t want = 2 * (uint64_t)s->hint[g] + 256;
+    plan.segcap[g] = (uint32_t)std::min(safe, want);
+    plan.threads[g] = plan.segcap[g] * QUEUE_SEGMENTS;
+    last = g;
+  }
+  int rc;
+  for (int g = 0; g <= last + 1 && g <= MAX_GENERATIONS; g++)
+    if ((rc = ensure_gen(s, g, g == 0 ? in.n0 : (size_t)plan.segcap[g] * QUEUE_SEGMENTS))) return rc;
+  *last_out = last;
+  return RT_OK;
+}
+
+static int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_stats* stats, bool* fits) {
+  GenPlan plan;
+  int last = 0, rc;
+  if ((rc = plan_speculative(s, in, max_gen, plan, &last))) return rc;
+  HIP_TRY(hipEventRecord(s->ev[0], main_stream(s)));
+  for (int g = 0; g <= last; g++) {
+    GenLaunch a;
+    fill_launch(s, in, plan, g, max_gen, a);
+    launch_generation(s, (g == 0 && in.camera) ? 1 : 2, false, a);
+  }
+  HIP_TRY(hipEventRecord(s->ev[1], main_stream(s)));
+  launch_resolves(s, in, plan, last);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, main_stream(s)));
+  HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                         main_stream(s)));
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
+  *fits = true;
+  int true_last = 0;
+  for (int g = 1; g <= max_gen && *fits; g++) {  // counters [g - 1]: the rays queued for generation g
+    uint32_t fullest = 0;
+    for (int k = 0; k < QUEUE_SEGMENTS; k++) fullest = std::max(fullest, s->h_counts[(g - 1) * QUEUE_SEGMENTS + k]);
+    if (fullest > plan.segcap[g]) *fits = false;
+    if (fullest == 0) break;
+    true_last = g;
+  }
+  if (!*fits) return RT_OK;
+  for (int g = 1; g <= MAX_GENERATIONS + 1; g++) {
+    uint32_t fullest = 0;
+    if (g <= true_last)
+      for (int k = 0; k < QUEUE_SEGMENTS; k++) fullest = std::max(fullest, s->h_counts[(g - 1) * QUEUE_SEGMENTS + k]);
+    s->hint[g] = fullest;
+  }
+  if (stats) {
+    decode_stats(s->h_stats, stats);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    stats->kernel_ms = ms;
+    stats->kernel_launches = (uint64_t)true_last + 1;
+    stats->generations = (uint64_t)true_last + 1;
+  }
+  return RT_OK;
+}
+
+// Runs the generations, resolves colours back into generation 0 and, for camera
+// rays, writes the image.  Fills the device-side fields of stats.
+int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
+  const bool count = (in.flags & RT_FLAG_COUNTERS) != 0;
+  int max_gen = std::min(std::max(in.remaining0, 0), RECURSION_DEPTH);
+  if (s->max_children == 0) max_gen = 0;
+  const bool direct = in.camera && max_gen == 0;  // every pixel is final after generation 0
+  static const bool no_speculation = getenv("RT_AMD_NO_SPECULATION") != nullptr;
+  const bool hinted = max_gen > 0 && !count && !no_speculation && s->hint_valid && s->hint_key[0] == in.n0 &&
+                      s->hint_key[1] == (uint32_t)in.remaining0;
+  if (hinted && s->holdoff > 0) {
+    s->holdoff--;
+  } else if (hinted) {
+    HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
+    HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
+    bool fits = false;
+    int rc = run_speculative(s, in, max_gen, stats, &fits);
+    if (rc) return rc;
+    if (fits) {
+      s->holdoff_next = 1;
+      return RT_OK;
+    }
+    // start over, one generation at a time, and stay exact for a while: a frame that does not fit is
+    // rendered twice, and a camera that moves this fast will do it again
+    s->holdoff = s->holdoff_next;
+    s->holdoff_next = std::min(2 * s->holdoff_next, 64u);
+    static const bool debug = getenv("RT_AMD_DEBUG") != nullptr;
+    if (debug) fprintf(stderr, "[rt_amd] speculative frame did not fit; exact for the next %u frames\n", s->holdoff);
+  }
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
+  if (max_gen > 0) HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
+  GenPlan plan;
+  uint32_t fullest[MAX_GENERATIONS + 2] = {0};
+  plan.threads[0] = in.n0;
+  int last = 0;
+  for (int g = 0; g <= max_gen && plan.threads[g] > 0; g++) {
+    last = g;
+    const uint64_t next_segcap = g < max_gen ? safe_segcap(plan.threads[g], s->max_children) : 0;
+    if (next_segcap * QUEUE_SEGMENTS > 0xFFFFFF00ull)
+      return fail(RT_ERR_UNSUPPORTED, "too many secondary rays for one generation");
+    plan.segcap[g + 1] = (uint32_t)next_segcap;
+    int rc;
+    if (!direct && g == 0 && (rc = ensure_gen(s, 0, in.n0))) return rc;
+    if ((rc = ensure_gen(s, g + 1, (size_t)next_segcap * QUEUE_SEGMENTS))) return rc;
+    GenLaunch a;
+    fill_launch(s, in, plan, g, max_gen, a);
+    int mode = (g == 0 && in.camera) ? (direct ? 0 : 1) : 2;
+    HIP_TRY(hipEventRecord(s->ev[g * 2 + 0], main_stream(s)));
+    launch_generation(s, mode, count, a);
+    HIP_TRY(hipEventRecord(s->ev[g * 2 + 1], main_stream(s)));
+    if (g < max_gen) {
+      uint32_t* h = s->h_counts + g * QUEUE_SEGMENTS;
+      HIP_TRY(hipMemcpyAsync(h, s->d_counts + g * QUEUE_SEGMENTS, QUEUE_SEGMENTS * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             main_stream(s)));
+      HIP_TRY(hipStreamSynchronize(main_stream(s)));
+      uint64_t total = 0;
+      for (int k = 0; k < QUEUE_SEGMENTS; k++) {
+        total += std::min<uint32_t>(h[k], (uint32_t)next_segcap);
+        fullest[g + 1] = std::max(fullest[g + 1], h[k]);
+      }
+      plan.threads[g + 1] = (uint32_t)total;
+    }
+#ifdef RT_STAMPS
+    {
+      static unsigned long long before[STAMP_WORDS];
+      if (g == 0) memset(before, 0, sizeof before);
+      HIP_TRY(hipStreamSynchronize(main_stream(s)));  // the generation just launched (the copy below does not wait for this stream)
+      HIP_TRY(hipMemcpy(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      const unsigned long long* t = s->h_stats + STAT_RAYS + 3 * STAT_SLOTS;
+      double d[STAMP_WORDS], sum = 0;
+      for (int k = 0; k < STAMP_WORDS; k++) { d[k] = (double)(t[k] - before[k]); before[k] = t[k]; }
+      for (int k = 0; k < 5; k++) sum += d[k];
+      const double waves = (double)((plan.threads[g] + BLOCK - 1) / BLOCK);
+      fprintf(stderr, "[rt_amd] generation %d rays %u: ticks per wave %.0f | raygen %.3f closest %.3f shade %.3f shadow %.3f output %.3f\n",
+              g, plan.threads[g], sum / waves, d[0] / sum, d[1] / sum, d[2] / sum, d[3] / sum, d[4] / sum);
+      fprintf(stderr, "[rt_amd]   closest: setup %.3f nodes %.3f tris %.3f quads/gates %.3f | shadow: setup %.3f nodes %.3f tris %.3f quads/gates %.3f\n",
+              d[8] / sum, d[9] / sum, d[10] / sum, d[11] / sum, d[16] / sum, d[17] / sum, d[18] / sum, d[19] / sum);
+      fprintf(stderr, "[rt_amd]   wave-level loop iterations: closest nodes %.0f tris %.0f quads %.0f rounds %.0f | shadow nodes %.0f tris %.0f quads %.0f rounds %.0f (waves %.0f)\n",
+              d[12], d[13], d[14], d[15], d[20], d[21], d[22], d[23], waves);
+    }
+#endif
+  }
+  launch_resolves(s, in, plan, last);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                         main_stream(s)));
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
+  if (max_gen > 0) {
+    for (int g = 0; g <= MAX_GENERATIONS + 1; g++) s->hint[g] = fullest[g];
+    s->hint_key[0] = in.n0;
+    s->hint_key[1] = (uint32_t)in.remaining0;
+    s->hint_valid = true;
+    if (!count && !no_speculation) {  // room for the next frame's queues now, not inside that frame
+      GenPlan next_plan;
+      int next_last = 0, rc;
+      if ((rc = plan_speculative(s, in, max_gen, next_plan, &next_last))) return rc;
+    }
+  }
+  if (stats) {
+    decode_stats(s->h_stats, stats);
+    stats->kernel_ms = 0;
+    stats->kernel_launches = 0;
+    stats->generations = (uint64_t)last + 1;
+    for (int g = 0; g <= last; g++) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, s->ev[g * 2 + 0], s->ev[g * 2 + 1]));
+      stats->kernel_ms += ms;
+      stats->kernel_launches++;
+    }
+  }
+  return RT_OK;
+}
+
+int stage_reserve(rt_scene* s, size_t bytes) {
+  if (s->stage_bytes >= bytes) return RT_OK;
+  if (s->stage) {
+    HIP_TRY(hipStreamSynchronize(main_stream(s)));
+    HIP_TRY(hipFree(s->stage));
+    s->stage = nullptr;
+    s->stage_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&s->stage, bytes));
+  s->stage_bytes = bytes;
+  return RT_OK;
+}
+
+}  // namespace rt

@@ -1,0 +1,114 @@
+// Ray records (one generation = struct of arrays in HBM), camera, image and statistics layout shared
+// by the kernels and the host pipeline.
+#pragma once
+#include "rt_math.h"
+
+namespace rt {
+
+struct GenView {
+  double *ox, *oy, *oz, *dx, *dy, *dz;              // ray (generations >= 1 and caller-supplied rays)
+  double *cr, *cg, *cb;                             // surface colour, then the ray's final colour
+  double *reflective, *transparency, *reflectance;  // mix factors of this hit
+  double* t;                                        // hit distance
+  uint32_t *child_reflect, *child_refract;          // indices into the next generation or REF_NONE
+  uint32_t* flags;                                  // bit0: hit, bit1: Schlick mix
+  int32_t* leaf;                                    // hit leaf or -1
+};
+
+DEV Ray load_ray(const GenView& g, uint32_t i) {
+  return Ray{v3(g.ox[i], g.oy[i], g.oz[i]), v3(g.dx[i], g.dy[i], g.dz[i])};
+}
+
+struct CameraDev {
+  uint32_t hsize, vsize;
+  double half_width, half_height, pixel_size;
+  double inv[12];
+};
+
+struct ImageOut {
+  uint8_t* rgb8;
+  double* rgb64;
+  int32_t* hit_leaf;
+  uint32_t compact;  // rgb8 holds this part's pixels in ray order (3 bytes at 3 i) instead of at y * width + x
+};
+
+// Arguments of one generation launch (host side).
+struct GenLaunch {
+  GenView cur, next;
+  uint32_t n, next_segcap;  // threads to launch; record slots per segment of the next generation's queue
+  int remaining;
+  uint32_t* next_counts;    // QUEUE_SEGMENTS counters
+  CameraDev cam;
+  const uint32_t* tiles;
+  uint32_t tiles_x;
+  ImageOut img;
+  unsigned long long* stats;
+  hipStream_t stream;
+  const uint32_t* queue_counts = nullptr;  // the segment counters this generation's rays were queued under
+  uint32_t segcap = 0;                     // (null: the rays are dense, n of them)
+};
+
+constexpr int TILE = 32;  // multi-GPU partition granule, pixels per side
+constexpr int TILE_PIXELS = TILE * TILE;
+constexpr int BLOCK = 64;  // threads per workgroup of every kernel: one wave
+// Thread index within the workgroup: the lane id, which costs two instructions to recompute wherever
+// it is needed instead of occupying a register for the whole kernel.
+DEV uint32_t thread_in_block() { return (uint32_t)__lane_id(); }
+
+// Device statistics block (unsigned long long): [0..3] closest-hit traversal work,
+// [4..7] shadow traversal work, then three ray counters spread over 64 slots each
+// (shaded hits = shadow rays, reflection rays, refraction rays) so that the per-wave
+// adds do not all land on one address.
+constexpr int STAT_SLOTS = 64;
+constexpr int QUEUE_SEGMENTS = 64;
+constexpr int COUNT_WORDS = (MAX_GENERATIONS + 1) * QUEUE_SEGMENTS;  // queue counters of one frame
+constexpr int STAT_RAYS = 8;
+#ifdef RT_STAMPS
+// Diagnostic build: per-wave clock stamps between the sections of k_generation, summed per section.
+constexpr int STAMP_WORDS = 24;  // 0..4 sections of k_generation, 8..11 / 16..19 closest, 12..15 / 20..23 shadow
+#else
+constexpr int STAMP_WORDS = 0;
+#endif
+constexpr int STAT_WORDS = STAT_RAYS + 3 * STAT_SLOTS + STAMP_WORDS;
+#ifdef RT_STAMPS
+#define RT_STAMP(k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    if ((thread_in_block() & 63) == 0) atomicAdd(&stats[STAT_RAYS + 3 * STAT_SLOTS + (k)], now_ - stamp_); stamp_ = now_; } while (0)
+#else
+#define RT_STAMP(k) do { } while (0)
+#endif
+
+// Ray index -> pixel: tile k of this part, then 8x8 pixel blocks per wave so the
+// 64 rays of a wave stay close in screen space.
+DEV bool ray_pixel(const uint32_t* tiles, uint32_t tiles_x, const CameraDev& cam, uint32_t i, uint32_t& x,
+                   uint32_t& y) {
+  uint32_t tile = tiles ? tiles[i / TILE_PIXELS] : i / TILE_PIXELS;  // no table: the part owns every tile, in order
+  uint32_t in_tile = i % TILE_PIXELS;
+  uint32_t wave = in_tile >> 6, lane = in_tile & 63u;
+  x = (tile % tiles_x) * TILE + (wave & 3u) * 8u + (lane & 7u);
+  y = (tile / tiles_x) * TILE + (wave >> 2) * 8u + (lane >> 3);
+  return x < cam.hsize && y < cam.vsize;
+}
+
+// Camera::ray_for_pixel (src/camera.rs:76-95) with the inverse precomputed.
+DEV Ray camera_ray(const CameraDev& cam, uint32_t px, uint32_t py) {
+  double xoffset = ((double)px + 0.5) * cam.pixel_size;
+  double yoffset = ((double)py + 0.5) * cam.pixel_size;
+  double world_x = cam.half_width - xoffset;
+  double world_y = cam.half_height - yoffset;
+  V3 pixel = mul_point(cam.inv, v3(world_x, world_y, -1.0));
+  V3 origin = mul_point(cam.inv, v3(0.0, 0.0, 0.0));
+  V3 direction = normalize(pixel - origin);
+  return Ray{origin, direction};
+}
+
+DEV void flush_counters(const Counters& c, unsigned long long* out) {
+  // one atomic per wave and counter
+  unsigned long long v[4] = {c.node_visits, c.tri_tests, c.quad_tests, c.gate_tests};
+  for (int k = 0; k < 4; k++) {
+    unsigned long long s = v[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((thread_in_block() & 63) == 0 && s) atomicAdd(&out[k], s);
+  }
+}
+
+}  // namespace rt

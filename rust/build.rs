@@ -26,8 +26,8 @@ fn main() {
     println!("cargo:rustc-link-search=native={}", lib.display());
     println!("cargo:rustc-link-lib=dylib=rt_amd");
     println!("cargo:rustc-link-arg=-Wl,-rpath,{}", lib.display());
-    for f in ["csrc/rt_device.hip", "csrc/ppm_device.hip", "csrc/band_grid_device.hip", "csrc/bvh_build.cpp",
-              "csrc/band_grid.cpp", "csrc/rt_types.h", "../include/rt_amd.h", "Makefile"] {
+    // a directory: cargo re-runs this script when any file below it changes
+    for f in ["csrc", "../include/rt_amd.h", "Makefile"] {
         println!("cargo:rerun-if-changed={}", dir.join(f).display());
     }
     println!("cargo:rerun-if-env-changed=RT_AMD_DIR");

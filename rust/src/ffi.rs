@@ -1,5 +1,5 @@
 //! `include/rt_amd.h` for Rust: every struct `#[repr(C)]` with the header's field order, every export
-//! declared.  Sizes and offsets are asserted on the C side (static_asserts in csrc/rt_device.hip) and
+//! declared.  Sizes and offsets are asserted on the C side (static_asserts in csrc/rt_api.cpp) and
 //! repeated here as compile-time checks.
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
@@ -91,7 +91,7 @@ pub struct rt_stats {
 }
 #[repr(C)] pub struct rt_scene { _private: [u8; 0] }
 
-// the sizes the C side asserts (csrc/rt_device.hip RT_ABI_SIZE)
+// the sizes the C side asserts (csrc/rt_api.cpp RT_ABI_SIZE)
 const _: [(); 384] = [(); std::mem::size_of::<rt_xform>()];
 const _: [(); 168] = [(); std::mem::size_of::<rt_triangle>()];
 const _: [(); 72] = [(); std::mem::size_of::<rt_leaf>()];
