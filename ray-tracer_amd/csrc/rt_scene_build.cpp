@@ -540,6 +540,14 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   delete s;
 }
 
+static void box_to_f32(const double lo[3], const double hi[3], float* out6) {
+  for (int a = 0; a < 3; a++) {
+    float l = (float)lo[a], h = (float)hi[a];
+    out6[a] = (double)l > lo[a] ? std::nextafterf(l, -INFINITY) : l;
+    out6[3 + a] = (double)h < hi[a] ? std::nextafterf(h, INFINITY) : h;
+  }
+}
+
 // Streams, events and the per-frame counters of a scene on `device` (which becomes current).
 static int scene_runtime_init(rt_scene* s, int device) {
   HIP_TRY(hipSetDevice(device));
@@ -815,6 +823,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
   if ((rc = upload(s, pats, &s->dev.patterns))) return rc;
   s->dev.root = root;
   s->dev.root_alt = b.bvh.alt(root);
+  if (root != REF_NONE) box_to_f32(lo, hi, s->dev.scene_box);  // the node planes are these boxes' subsets, rounded the same way
   {  // the host copy rt_scene_update works from
     rt_scene::Host& H = s->host;
     H.tris = tris;
@@ -974,14 +983,6 @@ static int reupload(rt_scene* s, size_t field, const std::vector<T>& v) {
   return RT_OK;
 }
 #define RT_FIELD(f) offsetof(SceneDev, f)
-
-static void box_to_f32(const double lo[3], const double hi[3], float* out6) {
-  for (int a = 0; a < 3; a++) {
-    float l = (float)lo[a], h = (float)hi[a];
-    out6[a] = (double)l > lo[a] ? std::nextafterf(l, -INFINITY) : l;
-    out6[3 + a] = (double)h < hi[a] ? std::nextafterf(h, INFINITY) : h;
-  }
-}
 
 static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
   rt_scene::Host& H = s->host;
@@ -1158,6 +1159,25 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
     HIP_TRY(hipStreamSynchronize(main_stream(s)));
   }
   s->dev.root_alt = s->dev.root;  // with every gate tested, both kinds of ray walk the same references
+  // the box of the whole hierarchy: from the root node's new planes, or none (everything passes)
+  for (int a = 0; a < 3; a++) {
+    s->dev.scene_box[a] = -INFINITY;
+    s->dev.scene_box[3 + a] = INFINITY;
+  }
+  if (s->dev.root != REF_NONE && (s->dev.root >> 30) == KIND_INNER) {
+    BvhNode top;
+    HIP_TRY(hipMemcpy(&top, s->dev.nodes + s->dev.root, sizeof top, hipMemcpyDeviceToHost));
+    for (int a = 0; a < 3; a++) {
+      float l = INFINITY, h = -INFINITY;
+      for (int c = 0; c < 4; c++)
+        if (top.child[c] != REF_NONE) {
+          l = fminf(l, top.plane[a][0][c]);
+          h = fmaxf(h, top.plane[a][1][c]);
+        }
+      s->dev.scene_box[a] = l;
+      s->dev.scene_box[3 + a] = h;
+    }
+  }
   H.tris.swap(tris);
   H.quads.swap(quads);
   H.unbounded.swap(unbounded);

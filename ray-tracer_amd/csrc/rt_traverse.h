@@ -420,6 +420,18 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
   const RayBox rb = make_raybox(ray, Query::BEHIND, widen);
   auto hi_f = [&]() { return __double2float_ru(Q.hi_d()); };  // the query's far bound, rounded up
   float qhi = hi_f();
+  {  // The box of the whole hierarchy comes with the kernel arguments: a ray that misses it (most rays of a
+     // floor) is done without fetching the root node.  Same test and constants as slab4, on a box that holds
+     // every child box, so it fails only where every child's test would.
+    float tnear = -INFINITY, tfar = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const bool neg = (rb.off_near[a] & 16u) != 0u;
+      tnear = fmaxf(tnear, fmaf(neg ? S.scene_box[3 + a] : S.scene_box[a], rb.inv_n[a], -rb.c_n[a]));
+      tfar = fminf(tfar, fmaf(neg ? S.scene_box[a] : S.scene_box[3 + a], rb.inv_f[a], -rb.c_f[a]));
+    }
+    if (!(fmaxf(tnear, 0.0f) <= fminf(tfar, qhi))) return;
+  }
   st.clear();
   // rays without a near-zero direction component read the child references in which skippable
   // gates are already replaced by their subtrees

@@ -218,6 +218,8 @@ struct SceneDev {
   // How far outside their exact shape the reference can report hits of round shapes for a ray from a
   // far origin (make_raybox): [0] sphere / cylinder term, [1] cone term, [2] largest |centre|^2 of a round shape.
   double box_noise[3];
+  // Box of everything in the hierarchy (lo xyz, hi xyz, rounded outward): a ray that misses it fetches no node.
+  float scene_box[6];
   InlinePlane inline_planes[MAX_INLINE_PLANES];
   double light_intensity[3];
   double light_position[3];
