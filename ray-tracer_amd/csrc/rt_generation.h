@@ -32,7 +32,7 @@ template <int STACK, bool COUNT, int MODE, bool CSG, bool UNIFORM, bool TRIPF = 
 __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : RT_MIN_WAVES_SPAWN)
     k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_segcap, int remaining,
                  uint32_t* next_counts, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
-                 uint32_t tiles_x, ImageOut img, const uint32_t* queue_counts, uint32_t segcap) {
+                 uint32_t tiles_x, ImageOut img, const uint32_t* queue_counts, uint32_t segcap, ShadowView aside) {
   __shared__ uint32_t lds[STACK * BLOCK];
   LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF> st;
   extern __shared__ uint32_t csg_lds[];  // SceneDev::csg_hits * 3 * BLOCK words when the scene has CSG operators, else nothing
@@ -98,7 +98,26 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
   uint32_t flags = hit ? 1u : 0u;
   if (hit) {
     const LeafShade L = S.leaves[leaf];
-    const MaterialDev m = S.materials[L.material];
+    const MaterialDev* material = S.materials + L.material;
+    // n1 / n2 (src/intersect.rs:191-234) first: the second walk then runs while little else is live
+    double n1 = 1.0, n2 = 1.0;
+    if (MODE != 0 && (material->flags & 8)) {  // they are consumed: refraction or Schlick
+      ContainerQuery C;
+      C.init(leaf);
+      traverse<ContainerQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, ray, C, st, ct);
+      double ri_hit = material->refractive_index;
+      double ri_other = C.other_leaf >= 0 ? S.materials[S.leaves[C.other_leaf].material].refractive_index : 1.0;
+      if (C.hit_inside) {
+        bool hit_last = C.other_leaf < 0 || C.hit_key > C.other_key ||
+                        (C.hit_key == C.other_key && C.hit_leaf > C.other_leaf);
+        n1 = hit_last ? ri_hit : ri_other;
+        n2 = ri_other;
+      } else {
+        n1 = ri_other;
+        n2 = ri_hit;
+      }
+    }
+    const MaterialDev m = *material;
     const XformDev& X = S.xforms[L.xform];
     const double t = Q.best_t;
     V3 point = ray.o + (ray.d * t);  // Ray4D::position
@@ -149,23 +168,6 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
       if (remaining != 0 && (m.flags & 1)) {
         want_reflect = true;
         reflect_ray = Ray{over_point, reflect(ray.d, normalv)};
-      }
-      double n1 = 1.0, n2 = 1.0;
-      if (m.flags & 8) {  // n1 / n2 are consumed: refraction or Schlick (src/intersect.rs:191-234)
-        ContainerQuery C;
-        C.init(leaf);
-        traverse<ContainerQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, ray, C, st, ct);
-        double ri_hit = m.refractive_index;
-        double ri_other = C.other_leaf >= 0 ? S.materials[S.leaves[C.other_leaf].material].refractive_index : 1.0;
-        if (C.hit_inside) {
-          bool hit_last = C.other_leaf < 0 || C.hit_key > C.other_key ||
-                          (C.hit_key == C.other_key && C.hit_leaf > C.other_leaf);
-          n1 = hit_last ? ri_hit : ri_other;
-          n2 = ri_other;
-        } else {
-          n1 = ri_other;
-          n2 = ri_hit;
-        }
       }
       // refracted_color (src/world.rs:181-215)
       if (remaining != 0 && (m.flags & 2)) {
@@ -244,6 +246,30 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
   // World::is_shadowed (src/world.rs:123-137), then the in_shadow branch of lighting
   double out_r = 0.0, out_g = 0.0, out_b = 0.0;  // World::color_at: no hit => black
   RT_STAMP(2);  // shading, spawning
+  // lighting() returns `ambient` in shadow and `ambient + diffuse + specular` otherwise
+  // (src/light.rs:135-173).  Where the two are the same bits -- the light behind the surface, or a
+  // material without diffuse and specular terms -- the answer of is_shadowed cannot reach the
+  // colour, and the query (still counted as a ray) is not traversed.
+  const bool decides = hit && (__double_as_longlong(ar) != __double_as_longlong(lr) ||
+                               __double_as_longlong(ag) != __double_as_longlong(lg) ||
+                               __double_as_longlong(ab) != __double_as_longlong(lb));
+  // A hit on a cone's extension (src/shape.rs:1089-1103) lies far from the hits of the lanes around it, and so
+  // does its shadow query: walked here, it would hold the whole wave until it is done.  Such queries are set
+  // aside (point, ambient colour, record) for k_shadow, which walks them in waves of their own and replaces
+  // the lit colour stored here where the point is in shadow.  When the queue is full the query stays.
+  bool walk = decides;
+  if (aside.segcap != 0u && S.n_bands > 0) {
+    const uint32_t seg = blockIdx.x % QUEUE_SEGMENTS;
+    const bool far = decides && Q.on_cone_extension();
+    const uint32_t k = wave_append(aside.counts + seg, far);
+    if (far && k < aside.segcap) {
+      const uint32_t e = seg * aside.segcap + k;
+      aside.px[e] = over_point.x; aside.py[e] = over_point.y; aside.pz[e] = over_point.z;
+      aside.ar[e] = ar; aside.ag[e] = ag; aside.ab[e] = ab;
+      aside.target[e] = rec;
+      walk = false;
+    }
+  }
   if (hit) {
     V3 lightpos = v3(S.light_position[0], S.light_position[1], S.light_position[2]);
     V3 v = lightpos - over_point;
@@ -251,14 +277,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
     SQ.distance = magnitude(v);
     SQ.found = false;
     Ray shadow_ray{over_point, normalize(v)};
-    // lighting() returns `ambient` in shadow and `ambient + diffuse + specular` otherwise
-    // (src/light.rs:135-173).  Where the two are the same bits -- the light behind the surface, or a
-    // material without diffuse and specular terms -- the answer of is_shadowed cannot reach the
-    // colour, and the query (still counted as a ray) is not traversed.
-    const bool decides = __double_as_longlong(ar) != __double_as_longlong(lr) ||
-                         __double_as_longlong(ag) != __double_as_longlong(lg) ||
-                         __double_as_longlong(ab) != __double_as_longlong(lb);
-    if (decides)
+    if (walk)
       traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, shadow_ray, SQ, st, cs);
     out_r = SQ.found ? ar : lr;
     out_g = SQ.found ? ag : lg;
@@ -303,12 +322,62 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
   RT_STAMP(4);  // output
 }
 
-// Launches the kernel of one generation for this combination of template arguments.  Defined where the
-// kernel is instantiated (rt_gen_*.hip); rt_launch.h declares it for the host pipeline.
+// The shadow queries a generation kernel set aside, one per lane in waves of their own: World::is_shadowed
+// (src/world.rs:123-137), then lighting()'s in_shadow branch (src/light.rs:135-141) for the points that
+// are: the ambient colour replaces the lit one the generation kernel stored -- in the ray's record when it
+// has one that is read again (mode 2: every ray; mode 1: camera rays with children), else in its pixel.
+template <int STACK, bool COUNT, bool CSG, bool UNIFORM>
+__global__ void __launch_bounds__(BLOCK, RT_MIN_WAVES)
+    k_shadow(SceneDev S, ShadowView q, uint32_t n, GenView g, int mode, unsigned long long* stats, CameraDev cam,
+             const uint32_t* tiles, uint32_t tiles_x, ImageOut img) {
+  __shared__ uint32_t lds[STACK * BLOCK];
+  LdsStack<STACK, BLOCK, CSG, UNIFORM, false> st;
+  extern __shared__ uint32_t csg_lds[];
+  st.init(lds, CSG ? csg_lds : nullptr);
+  const uint32_t i = blockIdx.x * BLOCK + thread_in_block();
+  uint32_t slot = 0;
+  const bool active = queue_slot(q.counts, q.segcap, i, slot) && i < n;  // n only bounds the grid
+  if (!__any(active)) return;
+  Counters cs{};
+  ShadowQuery SQ;
+  SQ.distance = 0.0;
+  SQ.found = false;
+  if (active) {
+    const V3 p = v3(q.px[slot], q.py[slot], q.pz[slot]);
+    const V3 v = v3(S.light_position[0], S.light_position[1], S.light_position[2]) - p;
+    SQ.distance = magnitude(v);
+    const Ray shadow_ray{p, normalize(v)};
+    traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, false>, COUNT>(S, shadow_ray, SQ, st, cs);
+  }
+  if (active && SQ.found) {
+    const uint32_t rec = q.target[slot];
+    const double r = q.ar[slot], gg = q.ag[slot], b = q.ab[slot];
+    if (mode == 2 || (mode == 1 && (g.flags[rec] & 4u))) {
+      g.cr[rec] = r; g.cg[rec] = gg; g.cb[rec] = b;
+    } else {
+      uint32_t x = 0, y = 0;
+      if (ray_pixel(tiles, tiles_x, cam, rec, x, y)) {
+        const size_t p = (size_t)y * cam.hsize + x;
+        if (img.rgb64) {
+          img.rgb64[p * 3 + 0] = r; img.rgb64[p * 3 + 1] = gg; img.rgb64[p * 3 + 2] = b;
+        }
+        if (img.rgb8) {
+          uint8_t* dst = img.rgb8 + (img.compact ? (size_t)rec : p) * 3;
+          dst[0] = quantise(r); dst[1] = quantise(gg); dst[2] = quantise(b);
+        }
+      }
+    }
+  }
+  if (COUNT) flush_counters(cs, stats + 4);
+}
+
+// Launches the kernel of one generation for this combination of template arguments, and after it the kernel
+// of the shadow queries it set aside (a.aside.segcap != 0: scenes with bounded cones).  Defined where the
+// kernels are instantiated (rt_gen_*.hip); rt_launch.h declares it for the host pipeline.
 template <int STACK, bool COUNT, bool CSG, bool UNIFORM, bool TRIPF>
 void launch_generation_variant(const SceneDev& dev, unsigned extra_lds, int mode, const GenLaunch& a) {
   dim3 grid((a.n + BLOCK - 1) / BLOCK), block(BLOCK);
-#define RT_GEN_ARGS dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap
+#define RT_GEN_ARGS dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap, a.aside
   if constexpr (TRIPF) {  // only camera rays of scenes that spawn nothing fetch triangles ahead
     hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG, UNIFORM, true>), grid, block, extra_lds, a.stream, RT_GEN_ARGS);
   } else {
@@ -319,6 +388,11 @@ void launch_generation_variant(const SceneDev& dev, unsigned extra_lds, int mode
     }
   }
 #undef RT_GEN_ARGS
+  if (a.aside.segcap != 0u) {  // the grid covers the queue's room; waves beyond its end exit at once
+    const uint32_t room = a.aside.segcap * QUEUE_SEGMENTS;
+    hipLaunchKernelGGL((k_shadow<STACK, COUNT, CSG, UNIFORM>), dim3((room + BLOCK - 1) / BLOCK), block, extra_lds, a.stream, dev,
+                       a.aside, room, a.cur, mode, a.stats, a.cam, a.tiles, a.tiles_x, a.img);
+  }
 }
 
 }  // namespace rt

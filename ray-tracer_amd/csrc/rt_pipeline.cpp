@@ -25,6 +25,31 @@ int rt::ensure_gen(rt_scene* s, int g, size_t cap) {
   return RT_OK;
 }
 
+// Entries per segment of the queue of shadow queries set aside by a generation of `rays` rays: an eighth of
+// what its waves could queue (they are dealt to the segments round-robin, at most 64 queries each); a query
+// that finds its segment full is walked in place.
+static inline uint32_t aside_segcap(uint32_t rays) {
+  const uint64_t waves = ((uint64_t)rays + BLOCK - 1) / BLOCK;
+  const uint64_t all = (waves + QUEUE_SEGMENTS - 1) / QUEUE_SEGMENTS * BLOCK;
+  return (uint32_t)((all / 8 + 63) & ~(uint64_t)63);
+}
+
+int rt::ensure_aside(rt_scene* s, uint32_t rays) {
+  ShadowBuf& b = s->aside_buf;
+  const size_t cap = (size_t)aside_segcap(rays) * QUEUE_SEGMENTS;
+  if (b.capacity >= cap) return RT_OK;
+  if (b.slab) {
+    HIP_TRY(hipStreamSynchronize(main_stream(s)));
+    HIP_TRY(hipFree(b.slab));
+    b.slab = nullptr;
+    b.capacity = 0;
+  }
+  HIP_TRY(hipMalloc(&b.slab, shadow_bytes(cap)));
+  b.capacity = cap;
+  carve(b);
+  return RT_OK;
+}
+
 namespace {
 
 // The kernel for this scene and generation: the instantiations live in rt_gen_*.hip.
@@ -195,6 +220,11 @@ static void fill_launch(rt_scene* s, const PipelineIn& in, const GenPlan& plan, 
   a.stream = main_stream(s);
   a.queue_counts = g > 0 ? s->d_counts + (g - 1) * QUEUE_SEGMENTS : nullptr;
   a.segcap = plan.segcap[g];
+  if (s->set_aside) {  // room was made by ensure_aside(plan.threads[g])
+    a.aside = s->aside_buf.view;
+    a.aside.counts = s->d_counts + COUNT_WORDS + g * QUEUE_SEGMENTS;
+    a.aside.segcap = aside_segcap(plan.threads[g]);
+  }
 }
 
 static void launch_resolve_generation(rt_scene* s, const GenPlan& plan, int g) {
@@ -228,6 +258,11 @@ static int plan_speculative(rt_scene* s, const PipelineIn& in, int max_gen, GenP
   int rc;
   for (int g = 0; g <= last + 1 && g <= MAX_GENERATIONS; g++)
     if ((rc = ensure_gen(s, g, g == 0 ? in.n0 : (size_t)plan.segcap[g] * QUEUE_SEGMENTS))) return rc;
+  if (s->set_aside) {
+    uint32_t most = 0;
+    for (int g = 0; g <= last; g++) most = std::max(most, plan.threads[g]);
+    if ((rc = ensure_aside(s, most))) return rc;
+  }
   *last_out = last;
   return RT_OK;
 }
@@ -290,7 +325,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     s->holdoff--;
   } else if (hinted) {
     HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
-    HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
+    HIP_TRY(hipMemsetAsync(s->d_counts, 0, ALL_COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
     bool fits = false;
     int rc = run_speculative(s, in, max_gen, stats, &fits);
     if (rc) return rc;
@@ -306,7 +341,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     if (debug) fprintf(stderr, "[rt_amd] speculative frame did not fit; exact for the next %u frames\n", s->holdoff);
   }
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
-  if (max_gen > 0) HIP_TRY(hipMemsetAsync(s->d_counts, 0, COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
+  if (max_gen > 0 || s->set_aside) HIP_TRY(hipMemsetAsync(s->d_counts, 0, ALL_COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
   GenPlan plan;
   uint32_t fullest[MAX_GENERATIONS + 2] = {0};
   plan.threads[0] = in.n0;
@@ -320,6 +355,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     int rc;
     if (!direct && g == 0 && (rc = ensure_gen(s, 0, in.n0))) return rc;
     if ((rc = ensure_gen(s, g + 1, (size_t)next_segcap * QUEUE_SEGMENTS))) return rc;
+    if (s->set_aside && (rc = ensure_aside(s, plan.threads[g]))) return rc;
     GenLaunch a;
     fill_launch(s, in, plan, g, max_gen, a);
     int mode = (g == 0 && in.camera) ? (direct ? 0 : 1) : 2;

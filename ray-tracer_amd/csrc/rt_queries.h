@@ -11,12 +11,17 @@ struct ClosestQuery {
   static constexpr bool BEHIND = false;
   double best_t;
   int best_leaf;
+  int band_leaf;  // the best hit when the cones' parallel-ray list had been looked through
   double u, v;
   DEV void init() {
     best_t = INFINITY;
-    best_leaf = 0x7FFFFFFF;
+    best_leaf = band_leaf = 0x7FFFFFFF;
     u = v = 0.0;
   }
+  DEV void after_bands() { band_leaf = best_leaf; }
+  // The hit came from a cone's parallel-ray branch (src/shape.rs:1089-1103), which can lie anywhere on the
+  // cone's infinite extension.  (A ray meets a cone either there or in the hierarchy, never in both.)
+  DEV bool on_cone_extension() const { return best_leaf != 0x7FFFFFFF && best_leaf == band_leaf; }
   DEV double hi_d() const { return best_t; }
   DEV bool done() const { return false; }
   DEV void offer(double t, int leaf, double uu, double vv) {
@@ -40,6 +45,7 @@ struct ShadowQuery {
   bool found;
   DEV double hi_d() const { return distance; }
   DEV bool done() const { return found; }
+  DEV void after_bands() {}
   DEV void leaf_ts(int, int n, const double* t) {
     for (int i = 0; i < n; i++)
       if (t[i] >= 0.0 && t[i] < distance) found = true;  // a finite bound keeps out +inf; NaN fails both
@@ -69,6 +75,7 @@ struct ContainerQuery {
   }
   DEV double hi_d() const { return INFINITY; }
   DEV bool done() const { return false; }
+  DEV void after_bands() {}
   DEV void container(int leaf, int count, double key) {
     if (!(count & 1)) return;
     if (leaf == hit_leaf) {

@@ -32,6 +32,17 @@ struct ImageOut {
   uint32_t compact;  // rgb8 holds this part's pixels in ray order (3 bytes at 3 i) instead of at y * width + x
 };
 
+// Shadow queries a generation kernel sets aside for a kernel of their own (k_shadow): World::is_shadowed
+// (src/world.rs:123-137) needs the point, and its answer picks between two colours lighting() can return
+// (src/light.rs:135-173); the generation kernel stored the lit one, the other travels with the query.
+struct ShadowView {
+  double *px, *py, *pz;  // over_point
+  double *ar, *ag, *ab;  // lighting()'s result in shadow: the ambient term
+  uint32_t* target;      // the ray's record (camera rays: the ray index, which names the pixel)
+  uint32_t* counts;      // QUEUE_SEGMENTS counters, zero before the generation runs
+  uint32_t segcap;       // entries per segment (0: no such queue)
+};
+
 // Arguments of one generation launch (host side).
 struct GenLaunch {
   GenView cur, next;
@@ -46,6 +57,8 @@ struct GenLaunch {
   hipStream_t stream;
   const uint32_t* queue_counts = nullptr;  // the segment counters this generation's rays were queued under
   uint32_t segcap = 0;                     // (null: the rays are dense, n of them)
+  // where the shadow queries of hits on a cone's extension go (segcap 0: nowhere, they are walked in place)
+  ShadowView aside{};
 };
 
 constexpr int TILE = 32;  // multi-GPU partition granule, pixels per side
@@ -61,7 +74,8 @@ DEV uint32_t thread_in_block() { return (uint32_t)__lane_id(); }
 // adds do not all land on one address.
 constexpr int STAT_SLOTS = 64;
 constexpr int QUEUE_SEGMENTS = 64;
-constexpr int COUNT_WORDS = (MAX_GENERATIONS + 1) * QUEUE_SEGMENTS;  // queue counters of one frame
+constexpr int COUNT_WORDS = (MAX_GENERATIONS + 1) * QUEUE_SEGMENTS;  // ray queue counters of one frame
+constexpr int ALL_COUNT_WORDS = 2 * COUNT_WORDS;  // ... then those of the shadow queries set aside
 constexpr int STAT_RAYS = 8;
 #ifdef RT_STAMPS
 // Diagnostic build: per-wave clock stamps between the sections of k_generation, summed per section.

@@ -41,6 +41,25 @@ inline void carve(GenBuf& b) {
   v.leaf = (int32_t*)(u + 3 * c);
 }
 
+// Room for the shadow queries of one generation (ShadowView): struct of arrays in one slab.
+struct ShadowBuf {
+  void* slab = nullptr;
+  size_t capacity = 0;  // entries
+  ShadowView view{};
+};
+inline size_t shadow_bytes(size_t cap) {
+  const size_t c = (cap + 63) & ~(size_t)63;
+  return c * (6 * sizeof(double) + sizeof(uint32_t));
+}
+inline void carve(ShadowBuf& b) {
+  const size_t c = (b.capacity + 63) & ~(size_t)63;
+  double* d = (double*)b.slab;
+  ShadowView& v = b.view;
+  v.px = d; v.py = d + c; v.pz = d + 2 * c;
+  v.ar = d + 3 * c; v.ag = d + 4 * c; v.ab = d + 5 * c;
+  v.target = (uint32_t*)(d + 6 * c);
+}
+
 }  // namespace rt
 
 struct rt_scene {
@@ -88,6 +107,9 @@ struct rt_scene {
   bool tri_prefetch = false;   // large mesh: kernels that fetch the next triangle of a run while one is tested
   int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
   rt::GenBuf gens[rt::MAX_GENERATIONS + 1];
+  // Shadow queries of hits on a cone's extension, walked by a kernel of their own (scenes with bounded cones)
+  bool set_aside = false;
+  rt::ShadowBuf aside_buf;
   uint32_t* d_counts = nullptr;           // [gen][QUEUE_SEGMENTS]: rays queued for the next generation, per segment
   unsigned long long* d_stats = nullptr;  // STAT_WORDS counters
   uint32_t* h_counts = nullptr;           // pinned mirrors
@@ -153,6 +175,7 @@ int attach_band_grid(rt_scene* s, size_t n_bands);
 // rt_pipeline.cpp
 int collect_all(rt_scene* s);  // waits for the frames in flight, then reads and clears the counters they added to
 int ensure_gen(rt_scene* s, int g, size_t cap);
+int ensure_aside(rt_scene* s, uint32_t rays);  // room for the shadow queries a generation of that many rays may set aside
 int stage_reserve(rt_scene* s, size_t bytes);
 bool affine(const double* m16);  // last row 0 0 0 1
 inline void copy3x4(double* dst, const double* src16) { memcpy(dst, src16, 12 * sizeof(double)); }

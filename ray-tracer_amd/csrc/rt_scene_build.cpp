@@ -506,6 +506,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   for (const rt_scene::Alloc& a : s->allocs) (void)hipFree(a.p);
   for (GenBuf& g : s->gens)
     if (g.slab) (void)hipFree(g.slab);
+  if (s->aside_buf.slab) (void)hipFree(s->aside_buf.slab);
   if (s->d_counts) (void)hipFree(s->d_counts);
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->h_counts) (void)hipHostFree(s->h_counts);
@@ -560,7 +561,7 @@ static int scene_runtime_init(rt_scene* s, int device) {
   HIP_TRY(hipEventCreateWithFlags(&s->copy_order, hipEventDisableTiming));
   for (hipEvent_t& e : s->copy_order2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (hipEvent_t& e : s->copy_fence) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIP_TRY(hipMalloc((void**)&s->d_counts, COUNT_WORDS * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc((void**)&s->d_counts, ALL_COUNT_WORDS * sizeof(uint32_t)));
   HIP_TRY(hipMalloc((void**)&s->d_stats, STAT_WORDS * sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc((void**)&s->h_counts, COUNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&s->h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
@@ -872,6 +873,10 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
   // loop (their kernels spill more than they gain).
   s->tri_prefetch = s->uniform_nodes && b.tri_src.size() * sizeof(TriIsect) >= (4u << 20);
   if (const char* e = getenv("RT_AMD_TRI_PREFETCH")) s->tri_prefetch = atoi(e) != 0;
+  // Scenes with bounded cones: the shadow queries of hits on a cone's extension are walked by a kernel of
+  // their own (k_shadow) instead of holding up the wave that found them.
+  s->set_aside = !b.bands.empty();
+  if (const char* e = getenv("RT_AMD_SET_ASIDE")) s->set_aside = atoi(e) != 0 && !b.bands.empty();
   s->dev.n_unbounded = (int32_t)b.unbounded.size();
   s->dev.n_leaves = d->n_leaves;
   for (int a = 0; a < 3; a++) {
@@ -1226,6 +1231,7 @@ extern "C" int rt_scene_clone(const rt_scene* src, int device, rt_scene** out) {
     s->has_csg = src->has_csg;
     s->uniform_nodes = src->uniform_nodes;
     s->tri_prefetch = src->tri_prefetch;
+    s->set_aside = src->set_aside;
     s->max_children = src->max_children;
     s->host = src->host;  // vectors copied; the refit's device arrays are made on the first update
     s->host.d_tri_box = s->host.d_quad_box = nullptr;

@@ -401,7 +401,10 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
   // their hits shorten the walk.  (A shadow query that walks the hierarchy first and looks the bands up
   // only when it found nothing was measured: correct, but the shadow ray of a hit far out on a cone's
   // extension runs back along that cone, and the band list ends it at once.)
-  if (S.n_bands > 0) band_list();
+  if (S.n_bands > 0) {
+    band_list();
+    Q.after_bands();
+  }
   auto hierarchy = [&]() {
   if (S.root == REF_NONE || Q.done()) return;
   const char* nodes = reinterpret_cast<const char*>(S.nodes);
