@@ -398,6 +398,12 @@ int rt_selftest_band_grid_device(int n_bands, uint64_t seed, int device, int* gr
 int rt_selftest_bvh_build(int n_items, uint64_t seed, int threads, uint64_t* hash, uint64_t* n_nodes,
                           double* seconds);
 
+/* Diagnostic, host only: the world-space normal the library stores for a plane or a flat triangle, whose
+ * normal is the same wherever it is hit: shape::normal_at (src/shape.rs:1478-1484) applied to the object-space
+ * normal, i.e. transposition(full_inv) * normal with w dropped, normalized, in the reference's operation
+ * order.  The kernels load this value instead of repeating the computation per hit. */
+int rt_selftest_world_normal(const double* full_inv16, const double* local_normal3, double* out3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,6 +153,34 @@ int orc_ray_for_pixel(void* h, uint64_t n, const uint32_t* xy, double* rays6) {
   return 0;
 }
 
+// shape::normal_at (shape.rs:1478-1484) of the depth-first leaf `leaf` at a world-space point, with the hit's
+// (u, v) for smooth triangles.  Returns 0, or -1 when there is no such leaf.
+static const Shape* find_leaf(const Shape& s, int leaf) {
+  if (s.ty == ShapeType::Group || s.is_csg()) {
+    for (const Shape& c : s.children)
+      if (const Shape* f = find_leaf(c, leaf)) return f;
+    return nullptr;
+  }
+  return s.leaf_id == leaf ? &s : nullptr;
+}
+int orc_leaf_normal_at(void* h, int leaf, const double* point3, double u, double v, double* out3, int* type_out) {
+  Scene* s = (Scene*)h;
+  for (const Shape& o : s->world.objects)
+    if (const Shape* f = find_leaf(o, leaf)) {
+      Intersection hit{};
+      hit.t = 1.0;
+      hit.what = f;
+      hit.has_uv = true;
+      hit.u = u;
+      hit.v = v;
+      Tuple n = normal_at(*f, point(point3[0], point3[1], point3[2]), hit);
+      out3[0] = n.x; out3[1] = n.y; out3[2] = n.z;
+      if (type_out) *type_out = (int)f->ty;
+      return 0;
+    }
+  return -1;
+}
+
 void orc_quantise(uint64_t n, const double* c, uint8_t* out) {
   for (uint64_t i = 0; i < n; i++) out[i] = (uint8_t)quantise(c[i]);
 }

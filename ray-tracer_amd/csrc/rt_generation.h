@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
 
   bool want_reflect = false, want_refract = false;
   Ray reflect_ray{v3(0, 0, 0), v3(0, 0, 0)}, refract_ray{v3(0, 0, 0), v3(0, 0, 0)};
-  V3 over_point = v3(0, 0, 0);
+  V3 over_point = v3(0, 0, 0), lightv = v3(0, 0, 0);
+  double light_distance = 0;
   double ar = 0, ag = 0, ab = 0, lr = 0, lg = 0, lb = 0;
   double k_reflective = 0, k_transparency = 0, reflectance = 0;
   uint32_t flags = hit ? 1u : 0u;
@@ -122,12 +123,19 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
     const double t = Q.best_t;
     V3 point = ray.o + (ray.d * t);  // Ray4D::position
     V3 eyev = -ray.d;
-    // normal_at (src/shape.rs:1478-1484)
-    V3 local_point = mul_point(X.full_inv, point);
-    V3 ln = local_normal(S, L, local_point, Q.u, Q.v);
-    const double* fi = X.full_inv;  // transposition() * normal, w dropped, normalize
-    V3 normalv = normalize(v3(fi[0] * ln.x + fi[4] * ln.y + fi[8] * ln.z, fi[1] * ln.x + fi[5] * ln.y + fi[9] * ln.z,
-                              fi[2] * ln.x + fi[6] * ln.y + fi[10] * ln.z));
+    // normal_at (src/shape.rs:1478-1484).  A plane and a flat triangle have one normal wherever they are hit:
+    // the host worked it out with these same operations (ShadingTables::build), and the point need not be
+    // taken to object space.
+    V3 normalv;
+    if (L.fixed_normal) {
+      normalv = v3(L.plane_normal[0], L.plane_normal[1], L.plane_normal[2]);
+    } else {
+      V3 local_point = mul_point(X.full_inv, point);
+      V3 ln = local_normal(S, L, local_point, Q.u, Q.v);
+      const double* fi = X.full_inv;  // transposition() * normal, w dropped, normalize
+      normalv = normalize(v3(fi[0] * ln.x + fi[4] * ln.y + fi[8] * ln.z, fi[1] * ln.x + fi[5] * ln.y + fi[9] * ln.z,
+                             fi[2] * ln.x + fi[6] * ln.y + fi[10] * ln.z));
+    }
     if (dot(normalv, eyev) < 0.0) normalv = -normalv;
     over_point = point + normalv * FEQ_EPSILON;
 
@@ -141,8 +149,10 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
       cr = m.color[0]; cg = m.color[1]; cb = m.color[2];
     }
     double er = cr * S.light_intensity[0], eg = cg * S.light_intensity[1], eb = cb * S.light_intensity[2];
-    V3 lightpos = v3(S.light_position[0], S.light_position[1], S.light_position[2]);
-    V3 lightv = normalize(lightpos - over_point);
+    // the vector to the light serves lighting() and is_shadowed() (src/light.rs:137, src/world.rs:124-128)
+    const V3 to_light = v3(S.light_position[0], S.light_position[1], S.light_position[2]) - over_point;
+    light_distance = magnitude(to_light);
+    lightv = to_light * (1.0 / light_distance);  // Tuple4D::normalize
     ar = er * m.ambient; ag = eg * m.ambient; ab = eb * m.ambient;
     double dr = 0.0, dg = 0.0, db = 0.0, sr = 0.0, sg = 0.0, sb = 0.0;
     double light_dot_normal = dot(lightv, normalv);
@@ -271,12 +281,10 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
     }
   }
   if (hit) {
-    V3 lightpos = v3(S.light_position[0], S.light_position[1], S.light_position[2]);
-    V3 v = lightpos - over_point;
     ShadowQuery SQ;
-    SQ.distance = magnitude(v);
+    SQ.distance = light_distance;
     SQ.found = false;
-    Ray shadow_ray{over_point, normalize(v)};
+    Ray shadow_ray{over_point, lightv};
     if (walk)
       traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, shadow_ray, SQ, st, cs);
     out_r = SQ.found ? ar : lr;

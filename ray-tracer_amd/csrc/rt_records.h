@@ -23,6 +23,7 @@ struct CameraDev {
   uint32_t hsize, vsize;
   double half_width, half_height, pixel_size;
   double inv[12];
+  double origin[3];  // inv * point(0, 0, 0), the same for every pixel (src/camera.rs:91)
 };
 
 struct ImageOut {
@@ -110,7 +111,7 @@ DEV Ray camera_ray(const CameraDev& cam, uint32_t px, uint32_t py) {
   double world_x = cam.half_width - xoffset;
   double world_y = cam.half_height - yoffset;
   V3 pixel = mul_point(cam.inv, v3(world_x, world_y, -1.0));
-  V3 origin = mul_point(cam.inv, v3(0.0, 0.0, 0.0));
+  V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
   V3 direction = normalize(pixel - origin);
   return Ray{origin, direction};
 }

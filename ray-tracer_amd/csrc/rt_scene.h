@@ -172,6 +172,7 @@ std::string& last_error_text();
 
 // rt_scene_build.cpp
 int attach_band_grid(rt_scene* s, size_t n_bands);
+void world_normal(const double* full_inv, const double* local_normal, double* out);  // of a plane or flat triangle
 // rt_pipeline.cpp
 int collect_all(rt_scene* s);  // waits for the frames in flight, then reads and clears the counters they added to
 int ensure_gen(rt_scene* s, int g, size_t cap);

@@ -175,6 +175,22 @@ bool leaf_box(const rt_leaf& L, const rt_xform& X, const rt_triangle* tri, doubl
   return true;
 }
 
+}  // namespace
+
+// normalize(transposition(full_inv) * vector(ln)) with w dropped, as shape::normal_at forms it
+// (src/shape.rs:1481-1483, src/matrix.rs:644-649, src/tuple.rs:111-135)
+void rt::world_normal(const double* fi, const double* ln, double* out) {
+  const double x = fi[0] * ln[0] + fi[4] * ln[1] + fi[8] * ln[2];
+  const double y = fi[1] * ln[0] + fi[5] * ln[1] + fi[9] * ln[2];
+  const double z = fi[2] * ln[0] + fi[6] * ln[1] + fi[10] * ln[2];
+  const double mag = sqrt(x * x + y * y + z * z);
+  out[0] = x * (1.0 / mag);
+  out[1] = y * (1.0 / mag);
+  out[2] = z * (1.0 / mag);
+}
+
+namespace {
+
 // The tables the shading code reads, from a description.
 struct ShadingTables {
   std::vector<LeafShade> leaves;
@@ -189,8 +205,16 @@ struct ShadingTables {
       const rt_leaf& L = d->leaves[i];
       LeafShade& o = leaves[i];
       o.type = L.type; o.closed = L.closed; o.material = L.material; o.xform = L.xform;
-      o.tri = L.tri; o.pad = 0; o.minimum = L.minimum; o.maximum = L.maximum;
+      o.tri = L.tri; o.fixed_normal = 0; o.minimum = L.minimum; o.maximum = L.maximum;
       for (int a = 0; a < 3; a++) o.plane_normal[a] = L.plane_normal[a];
+      // normal_at (src/shape.rs:1478-1484) of a shape with one normal: transposition() * local normal, w dropped,
+      // normalized -- the operations and their order are those of the generation kernel, which then only loads it
+      const bool flat = L.type == RT_TRIANGLE && L.tri >= 0 && L.tri < d->n_triangles;
+      if ((L.type == RT_PLANE || flat) && L.xform >= 0 && L.xform < d->n_xforms) {
+        const double* ln = flat ? d->triangles[L.tri].normal : L.plane_normal;
+        world_normal(d->xforms[L.xform].full_inv, ln, o.plane_normal);
+        o.fixed_normal = 1;
+      }
     }
     xforms.resize(d->n_xforms);
     for (int i = 0; i < d->n_xforms; i++) {

@@ -155,3 +155,9 @@ extern "C" int rt_selftest_band_grid(int n_bands, int n_dirs, uint64_t seed, int
   }
   return missing;
 }
+
+extern "C" int rt_selftest_world_normal(const double* full_inv16, const double* local_normal3, double* out3) {
+  if (!full_inv16 || !local_normal3 || !out3) return fail(RT_ERR_INVALID, "rt_selftest_world_normal: null argument");
+  world_normal(full_inv16, local_normal3, out3);
+  return RT_OK;
+}

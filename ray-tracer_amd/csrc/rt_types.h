@@ -137,9 +137,9 @@ struct CsgLeaf {
 struct LeafShade {
   int32_t type, closed, material, xform;
   int32_t tri;  // triangle index or -1
-  int32_t pad;
+  int32_t fixed_normal;  // 1: plane_normal is the world-space unit normal of the whole shape (planes, flat triangles)
   double minimum, maximum;
-  double plane_normal[3];
+  double plane_normal[3];  // a plane's object-space normal, or the normal fixed_normal speaks of
 };
 static_assert(sizeof(LeafShade) == 64, "LeafShade layout");
 

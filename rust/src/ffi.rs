@@ -152,6 +152,7 @@ extern "C" {
                                         host_seconds: *mut f64, device_seconds: *mut f64) -> c_int;
     pub fn rt_selftest_bvh_build(n_items: c_int, seed: u64, threads: c_int, hash: *mut u64, n_nodes: *mut u64,
                                  seconds: *mut f64) -> c_int;
+    pub fn rt_selftest_world_normal(full_inv16: *const f64, local_normal3: *const f64, out3: *mut f64) -> c_int;
 }
 
 /// A negative status becomes a panic with the library's message: the reference panics on every failure

@@ -224,3 +224,58 @@ def test_random_scenes_flatten_like_the_oracle_tree(pkg, seed, tmp_path):
         ref = orc.OracleScene(text, base_dir=ROOT)
         assert s.info()["leaves"] == ref.info()["leaves"]
         assert (s.info()["width"], s.info()["height"]) == (ref.info()["width"], ref.info()["height"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_stored_world_normals_equal_normal_at(pkg, seed, tmp_path):
+    """Planes and flat triangles have one normal wherever they are hit.  The library stores
+    shape::normal_at's result for them (src/shape.rs:1478-1484: transposition(full_inv) * normal, w dropped,
+    normalized) when a scene is created and the kernels load it instead of recomputing it per hit: the stored
+    value must equal the oracle's normal_at bit for bit, under random transforms nested three groups deep."""
+    import test_gpu_fuzz as fuzz
+
+    class Leaf(ctypes.Structure):  # rt_leaf of include/rt_amd.h
+        _fields_ = [(n, ctypes.c_int32) for n in ("type", "closed", "material", "xform", "gate", "tri", "csg", "csg_left")] + [
+            ("minimum", ctypes.c_double), ("maximum", ctypes.c_double), ("plane_normal", ctypes.c_double * 3)]
+
+    class Xform(ctypes.Structure):  # rt_xform
+        _fields_ = [("ray_inv", ctypes.c_double * 16), ("full_inv", ctypes.c_double * 16), ("fwd", ctypes.c_double * 16)]
+
+    class Triangle(ctypes.Structure):  # rt_triangle
+        _fields_ = [(n, ctypes.c_double * 3) for n in ("p1", "e1", "e2", "normal", "n1", "n2", "n3")]
+
+    class Desc(ctypes.Structure):  # rt_scene_desc
+        _fields_ = [("light", ctypes.c_double * 6)] + [(n, ctypes.c_int32) for n in (
+            "n_leaves", "n_gates", "n_xforms", "n_triangles", "n_materials", "n_patterns", "n_csg", "n_chain_mats")] + [
+            ("csg", ctypes.c_void_p), ("leaves", ctypes.POINTER(Leaf)), ("gates", ctypes.c_void_p), ("xforms", ctypes.POINTER(Xform)),
+            ("triangles", ctypes.POINTER(Triangle))]
+
+    assert ctypes.sizeof(Leaf) == 72 and ctypes.sizeof(Xform) == 384 and ctypes.sizeof(Triangle) == 168
+    amd, host = pkg.libraries()
+    host.rth_scene_desc.restype = ctypes.POINTER(Desc)
+    host.rth_scene_desc.argtypes = [ctypes.c_void_p]
+    fn = amd.rt_selftest_world_normal
+    fn.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3
+    olib = orc.lib()
+    olib.orc_leaf_normal_at.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_double,
+                                        ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(seed)
+    checked = 0
+    for text in (fuzz.random_scene(seed), fuzz.mesh_scene(seed, str(tmp_path / "soup.obj"))):
+        s = pkg.Scene(text, ROOT, device=None)
+        ref = orc.OracleScene(text, base_dir=ROOT)
+        d = host.rth_scene_desc(s._h).contents
+        for li in range(d.n_leaves):
+            L = d.leaves[li]
+            if L.type not in (2, 6):  # RT_PLANE, RT_TRIANGLE
+                continue
+            ln = d.triangles[L.tri].normal if L.type == 6 else L.plane_normal
+            got = (ctypes.c_double * 3)()
+            assert fn(d.xforms[L.xform].full_inv, ln, got) == 0
+            want, ty = (ctypes.c_double * 3)(), ctypes.c_int()
+            at = (ctypes.c_double * 3)(*rng.uniform(-20, 20, 3))  # the point does not matter for these shapes
+            assert olib.orc_leaf_normal_at(ref._h, li, at, 0.25, 0.5, want, ctypes.byref(ty)) == 0
+            a, b = np.array(got[:]), np.array(want[:])
+            assert a.tobytes() == b.tobytes() or (np.isnan(a) == np.isnan(b)).all() and (a[~np.isnan(a)] == b[~np.isnan(b)]).all(), (li, a, b)
+            checked += 1
+    assert checked > 0
