@@ -7,9 +7,10 @@ exactly those bands over its own PCIe link into one page-locked host frame; ther
 exchange.  `python bench.py --gpus N` is one process that drives N GPUs with one native worker thread
 per GPU (the host library's FrameLoop, the many-frame form of parallel_render, src/parallel.rs:183-204).
 With fewer GPUs than N the parts are dealt round-robin over the GPUs there are (a rehearsal; the line
-says so).  Launched by torch.distributed.run with one rank per GPU (WORLD_SIZE > 1) every rank runs the same loop for
-its own part and the ranks assemble the frames in one shared-memory ring (bench_ranks; --rccl-gather selects
-the variant that gathers the parts on rank 0 with RCCL instead).
+says so).  Launched by torch.distributed.run with one rank per GPU (WORLD_SIZE > 1), rank 0 runs that same loop over all N
+GPUs, so that the whole frame lies in one page-locked host frame when the clock stops, and the other ranks take part
+in the barriers and the MAX over the ranks' times (bench_launched; --per-rank-loops lets every rank render and copy
+its own part into host memory of its own instead, --rccl-gather gathers the parts on rank 0 with RCCL).
 
 A ray is one World::intersect query of the reference algorithm (primary, shadow, reflection,
 refraction).  The scene stays resident in HBM; scene load and the BVH build are outside the timed
@@ -138,7 +139,10 @@ def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
     }
 
 
-def bench_single_process(args):
+def bench_single_process(args, timed=None):
+    """One process drives all N GPUs (one native worker thread per GPU); every frame is complete in one page-locked
+    host frame when the clock stops.  timed: under a launcher, the bracket every rank takes part in (barrier and
+    device synchronisation on both sides, MAX over the ranks' times); None: the native loop's own clock."""
     pkg = load_package()
     have = pkg.bindings.device_count()
     if have < 1:
@@ -155,15 +159,24 @@ def bench_single_process(args):
 
     # The timed region of the metric: frames on the host.  Then the same frames left in HBM, frames
     # rendered one at a time (lone launches), and one instrumented frame.
+    def leg(to_host):
+        if timed is None:  # the loop's own clock: K frames between two rendezvous of its workers with idle GPUs
+            return loop.run(args.warmup, args.steps, to_host)
+        if args.warmup > 0:
+            loop.run(0, args.warmup, to_host)  # untimed, ends with the GPUs idle
+        dt, (_, stats) = timed(lambda: loop.run(0, args.steps, to_host))
+        return dt, stats
+
     loop.run(0, PRIMING, not args.hbm_only)  # untimed
     if args.hbm_only:  # profiling aid: rocprofv3 turns the DMA copies into copy kernels that share the GPU with the render
-        host_s, host_stats = loop.run(args.warmup, args.steps, False)
+        host_s, host_stats = leg(False)
         sha, hbm_s = None, None
     else:
-        host_s, host_stats = loop.run(args.warmup, args.steps, True)
-        frame = loop.host_frame((args.warmup + args.steps - 1) % DEPTH).copy()
+        host_s, host_stats = leg(True)
+        last_slot = (args.steps - 1) % DEPTH if timed is not None else (args.warmup + args.steps - 1) % DEPTH
+        frame = loop.host_frame(last_slot).copy()
         sha = hashlib.sha256(frame.tobytes()).hexdigest()
-        hbm_s = None if args.no_hbm_leg else loop.run(args.warmup, args.steps, False)[0]
+        hbm_s = None if args.no_hbm_leg else leg(False)[0]
     lone = sum_stats(loop.blocking_frames(10, False))
     counted = sum_stats(loop.blocking_frames(1, True))
     piped = sum_stats(host_stats)
@@ -186,11 +199,18 @@ def bench_single_process(args):
         for t in threads:
             t.start()
         gate.wait()  # every loop warm, every GPU idle
-        t0 = time.perf_counter()
-        gate.wait()
-        for t in threads:
-            t.join()
-        dealt = time.perf_counter() - t0
+
+        def run_all():
+            gate.wait()
+            for t in threads:
+                t.join()
+
+        if timed is None:
+            t0 = time.perf_counter()
+            run_all()
+            dealt = time.perf_counter() - t0
+        else:
+            dealt = timed(run_all)[0]
         for lp in loops:
             lp.close()
     roofline = roofline_of(counted, lone, piped, linfo["scene_bytes"], host_s / args.steps, n)
@@ -250,7 +270,10 @@ def bench_single_process(args):
             "timed_region": "frames left in HBM (--hbm-only: a profiling run, not the metric's region)" if args.hbm_only
                             else "ray generation to the finished frame in page-locked host memory",
             "parallelism": "one process, %d part(s) = bands of 32 pixel rows dealt round-robin, one worker thread, one scene copy "
-                           "and one PCIe link per GPU, all parts copied into one shared host frame; no collective" % n,
+                           "and one PCIe link per GPU, all parts copied into one shared host frame; no collective" % n + (
+                               "" if timed is None else "; started by a launcher with one rank per GPU: rank 0 drives the GPUs, the "
+                               "other ranks hold their GPU and take part in the barriers and the MAX over the ranks' times"),
+            "frame_assembled_in_timed_region": True,
             "devices": devices,
             "rehearsal": have < n,
         },
@@ -276,6 +299,57 @@ def bench_single_process(args):
         out["config"]["note"] = "only %d GPU(s) visible: the %d parts share them, so this line rehearses the path and is no scaling figure" % (have, n)
     print(json.dumps(out))
     loop.close()
+
+
+def bench_launched(args, world):
+    """Started by torch.distributed.run with one rank per GPU.  The frame has to lie whole in one host buffer when
+    the clock stops (the reference fills one canvas, src/parallel.rs:186, 194-201).  Page-locked memory cannot be
+    shared between processes on the machines this was built on (hipHostRegister refuses shared mappings), so rank 0
+    runs the one-process loop over all N GPUs -- one worker thread, one scene copy and one PCIe link per GPU, every
+    GPU copying its bands by DMA into the same page-locked frame -- while every other rank holds its GPU and takes
+    part in what the launcher form of the bench asks of all ranks: a barrier and a device synchronisation on both
+    sides of the K timed frames and the MAX over the ranks' times.  No collective on the data path.
+    --per-rank-loops selects the arrangement in which every rank renders and copies its own part (bench_ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")  # gloo: a rehearsal on a machine with fewer GPUs than ranks
+    have = max(1, torch.cuda.device_count())
+    dev_index = local_rank % have if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+        red_device = device
+    else:
+        dist.init_process_group(backend)
+        red_device = torch.device("cpu")
+    torch.zeros(1, device=device)  # every rank initialises its GPU
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(work):
+        sync()
+        t0 = time.perf_counter()
+        result = work() if work is not None else None
+        sync()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item()), result
+
+    if rank == 0:
+        bench_single_process(args, timed)
+    else:  # the same brackets, in the same order, with nothing between them
+        legs = 1 + (0 if (args.no_hbm_leg or args.hbm_only) else 1) + (0 if (args.no_dealt_leg or args.hbm_only) else 1)
+        for _ in range(legs):
+            timed(None)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def bench_ranks(args, world):
@@ -392,7 +466,8 @@ def bench_ranks(args, world):
     roofline["frac_per_frame_period"] = flops_frame / (host_s / args.steps) / (FP64_VALU_PEAK * world)
     if rank == 0:
         print(json.dumps({
-            "metric": "rays/sec (node) on scenes/teapot.json at 1080p",
+            "metric": "rays/sec (node) on scenes/teapot.json at 1080p" + (
+                "" if assembled_by_dma else ", every rank's part in host memory of its own (frame not assembled)"),
             "value": rays_per_frame * args.steps / host_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": host_s / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -406,6 +481,7 @@ def bench_ranks(args, world):
                     "the timed region: that needs hipHostRegister on a shared mapping, RT_BENCH_SHARED_RING=1, which the "
                     "machines this was built on refuse)"),
                 "frame_assembled_by_dma_in_shared_memory": assembled_by_dma,
+                "frame_assembled_in_timed_region": bool(assembled_by_dma),
                 "parallelism": "one rank per GPU, %d parts = bands of 32 pixel rows dealt round-robin, scene replicated, each "
                                "rank copies its bands over its own PCIe link into the shared frame; no collective on the "
                                "data path" % world,
@@ -572,6 +648,9 @@ def main():
                          "turns the DMA copies to the host into copy kernels that share the GPU with the render kernel)")
     ap.add_argument("--no-dealt-leg", action="store_true",
                     help="N > 1: skip the extra leg that deals whole frames to the GPUs")
+    ap.add_argument("--per-rank-loops", action="store_true",
+                    help="under a launcher with one rank per GPU: every rank renders and copies its own part into a page-locked "
+                         "ring of its own; the frame is then not put together inside the timed region (the line says so)")
     ap.add_argument("--rccl-gather", action="store_true",
                     help="under a launcher with one rank per GPU: gather the parts on rank 0 with RCCL instead of "
                          "letting every rank copy its bands into the shared host frame")
@@ -585,7 +664,12 @@ def main():
     if world > 1:
         if world != args.gpus:
             raise SystemExit("--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world))
-        (bench_ranks_rccl_gather if args.rccl_gather else bench_ranks)(args, world)
+        if args.rccl_gather:
+            bench_ranks_rccl_gather(args, world)
+        elif args.per_rank_loops:
+            bench_ranks(args, world)
+        else:
+            bench_launched(args, world)
     else:
         bench_single_process(args)
 

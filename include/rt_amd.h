@@ -234,11 +234,17 @@ int rt_scene_build_info(const rt_scene* scene, uint64_t* device_builds, double* 
  * it.  The acceleration structure keeps its shape and gets new boxes (a refit on the GPU, no rebuild);
  * a hierarchy refitted many times over large motions traverses slower than a rebuilt one.  From the
  * first update on every group's bounding-box gate is evaluated exactly as the reference does it (the
- * shortcut for gates that provably contain their subtree needs a rebuild).  Returns
- * RT_ERR_UNSUPPORTED when the update needs a rebuild: a shape crossed between bounded and unbounded
- * (scaled beyond 100, see RT_ERR_UNSUPPORTED above), a transform chain changed its length, or the scene
- * has CSG operators.  Blocks until frames in flight are done and the update is complete. */
+ * shortcut for gates that provably contain their subtree needs a rebuild).  Where the hierarchy cannot
+ * keep its shape -- a shape crossed between bounded and unbounded (scaled beyond 100, see
+ * RT_ERR_UNSUPPORTED above), a transform chain changed its length (an identity level became a transform
+ * or the reverse), or the scene has CSG operators -- the acceleration structure is built again with the
+ * builder the scene was created with; the handle, its streams and frame buffers stay (rt_scene_rebuilds
+ * counts these).  Blocks until frames in flight are done and the update is complete.  An update that fails
+ * before any device table was written leaves the scene as it was; one that fails later leaves it unusable
+ * (rendering returns RT_ERR_INVALID) until an update succeeds. */
 int rt_scene_update(rt_scene* scene, const rt_scene_desc* desc);
+/* How many updates of this scene built the acceleration structure again instead of refitting it. */
+int rt_scene_rebuilds(const rt_scene* scene, uint64_t* rebuilds);
 
 /* A copy of `scene` on `device` (the same GPU or another one of this process): the acceleration structure
  * is not built again, its arrays are copied device to device.  The copy is independent of the original
@@ -361,8 +367,10 @@ int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width, uint64_t 
  * rt_host_alloc move fastest).  When capacity is too small, *length still receives the size needed. */
 int rt_ppm_encode_host(int device, const uint8_t* rgb8_host, uint64_t width, uint64_t height, char* out_host,
                        uint64_t capacity, uint64_t* length);
-/* rt_ppm_encode for callers that cannot allocate device memory (code under HIP graph capture, serving
- * loops and harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
+/* rt_ppm_encode for callers that cannot allocate device memory (serving loops and harnesses that forbid
+ * hipMalloc).  It allocates nothing but it is a blocking call like rt_ppm_encode: it launches on the null
+ * stream and waits for the file's length, so it is not for use while a stream is being captured into a
+ * graph.  No counterpart in the reference.  Same arguments, same
  * result byte for byte, but the workspace is a fixed array in the library's device image (about 18.4 MB
  * on every GPU the library runs on, held until the process ends) instead of a hipMalloc per call, and the
  * call makes no allocation of its own.  Frames of more than rt_ppm_static_max_pixels() pixels (one

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -392,8 +393,10 @@ done:
 }  // namespace
 
 // ---------------------------------------------------------------------------
-// The same encoder for callers that cannot allocate (code under HIP graph capture, serving loops that
-// forbid hipMalloc): the workspace is a fixed array in the library's device image, one copy per GPU.
+// The same encoder for callers that cannot allocate (serving loops and harnesses that forbid hipMalloc):
+// the workspace is a fixed array in the library's device image, one copy per GPU.  Like rt_ppm_encode it
+// blocks until the file is written (it launches on the null stream and waits for the length), so it is not
+// for use while a stream is being captured into a graph.
 // ---------------------------------------------------------------------------
 namespace {
 constexpr uint64_t PPM_STATIC_MAX_PIXELS = 3840ull * 2160ull;  // one 4K frame
@@ -425,6 +428,11 @@ int scratch_on_current_device(int device, char** out) {
 // One call at a time works in a GPU's array: calls on one GPU take turns.
 std::mutex g_scratch_turn[PPM_MAX_DEVICES];
 
+bool env_flag(const char* name) {
+  const char* e = getenv(name);
+  return e && *e && *e != '0';
+}
+
 // The encoder in the fixed workspace of `device` (current, frame within PPM_STATIC_MAX_PIXELS).  wait_for_turn:
 // block until the array is free; otherwise return at once with *ran = false when another call is using it.
 int ppm_run_in_scratch(int device, bool wait_for_turn, const uint8_t* rgb8_dev, uint64_t width, uint64_t height, char* out_dev,
@@ -435,7 +443,7 @@ int ppm_run_in_scratch(int device, bool wait_for_turn, const uint8_t* rgb8_dev, 
   else if (!turn.try_lock()) return RT_OK;
   char* ws = nullptr;
   int rc = scratch_on_current_device(device, &ws);
-  if (rc != RT_OK) return rc;
+  if (rc != RT_OK) return wait_for_turn ? rc : RT_OK;  // a caller that may allocate does so instead (*ran stays false)
   *ran = true;
   // nothing in the workspace has to start at zero: every word a kernel reads was written earlier in the same call
   return ppm_run(ws, rgb8_dev, width, height, out_dev, length, nullptr);
@@ -453,7 +461,8 @@ extern "C" int rt_ppm_encode(int device, const uint8_t* rgb8_dev, uint64_t width
   bool ran = false;
   PPM_TRY(hipGetDevice(&previous));
   PPM_TRY(hipSetDevice(device));
-  if (width * height <= PPM_STATIC_MAX_PIXELS && device >= 0 && device < PPM_MAX_DEVICES) {
+  // RT_AMD_PPM_ALLOCATE=1 (read per call): always allocate, as every call did before the fixed array existed
+  if (width * height <= PPM_STATIC_MAX_PIXELS && device >= 0 && device < PPM_MAX_DEVICES && !env_flag("RT_AMD_PPM_ALLOCATE")) {
     rc = ppm_run_in_scratch(device, false, rgb8_dev, width, height, out_dev, length, &ran);
     if (rc != RT_OK || ran) goto done;
   }

@@ -140,6 +140,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   if (camera->hsize == 0 || camera->vsize == 0) return fail(RT_ERR_INVALID, "empty canvas");
   if (!affine(camera->inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) camera transform");
   auto w0 = std::chrono::steady_clock::now();
+  RT_REQUIRE_USABLE(s);
   HIP_TRY(hipSetDevice(s->device));
   if (stats) memset(stats, 0, sizeof(*stats));
   uint32_t tiles_x = (camera->hsize + TILE - 1) / TILE, tiles_y = (camera->vsize + TILE - 1) / TILE;
@@ -362,6 +363,7 @@ extern "C" int rt_color_at(rt_scene* s, uint64_t n, const double* rays6, int rem
   if (!s || (n && (!rays6 || !rgb))) return fail(RT_ERR_INVALID, "null argument");
   if (remaining < 0) return fail(RT_ERR_INVALID, "remaining must be >= 0");
   if (remaining > RECURSION_DEPTH) return fail(RT_ERR_UNSUPPORTED, "remaining above the reference's depth of 5");
+  RT_REQUIRE_USABLE(s);
   HIP_TRY(hipSetDevice(s->device));
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n == 0) return RT_OK;
@@ -391,6 +393,7 @@ extern "C" int rt_color_at(rt_scene* s, uint64_t n, const double* rays6, int rem
 
 extern "C" int rt_intersect_hit(rt_scene* s, uint64_t n, const double* rays6, double* t, int32_t* leaf) {
   if (!s || (n && (!rays6 || !t || !leaf))) return fail(RT_ERR_INVALID, "null argument");
+  RT_REQUIRE_USABLE(s);
   HIP_TRY(hipSetDevice(s->device));
   if (n == 0) return RT_OK;
   int rc = load_user_rays(s, n, rays6);
@@ -408,6 +411,7 @@ extern "C" int rt_intersect_hit(rt_scene* s, uint64_t n, const double* rays6, do
 
 extern "C" int rt_is_shadowed(rt_scene* s, uint64_t n, const double* points3, uint8_t* shadowed) {
   if (!s || (n && (!points3 || !shadowed))) return fail(RT_ERR_INVALID, "null argument");
+  RT_REQUIRE_USABLE(s);
   HIP_TRY(hipSetDevice(s->device));
   if (n == 0) return RT_OK;
   if (n > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "too many points in one call");

@@ -97,6 +97,11 @@ struct rt_scene {
   size_t device_builds = 0;         // subtrees the GPU builder made
   int stack_need = 1;
   bool has_csg = false;
+  uint32_t build_flags = 0;  // of rt_scene_create_with: an update that has to build again builds the same way
+  uint64_t rebuilds = 0;     // updates that built the acceleration structure again instead of refitting it
+  // A failed rt_scene_update may have replaced some of the device tables and not others: such a scene refuses to
+  // render until an update succeeds.
+  bool broken = false;
   // queue lengths per generation of the last multi-generation frame: the next frame is launched on them
   // without asking the device after every generation
   uint32_t hint[rt::MAX_GENERATIONS + 2] = {0};  // [g]: the fullest queue segment of generation g
@@ -169,6 +174,9 @@ inline hipStream_t main_stream(rt_scene* s) {
 // Stores msg as the calling thread's rt_last_error() text and returns code.
 int fail(int code, const std::string& msg);
 std::string& last_error_text();
+
+// every entry point that traces rays through a scene starts with this
+#define RT_REQUIRE_USABLE(s) do { if ((s)->broken) return rt::fail(RT_ERR_INVALID, "the scene is unusable: an rt_scene_update failed half way; update it again or destroy it"); } while (0)
 
 // rt_scene_build.cpp
 int attach_band_grid(rt_scene* s, size_t n_bands);

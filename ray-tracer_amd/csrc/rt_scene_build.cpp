@@ -690,6 +690,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
 
   int rci = scene_runtime_init(s, device);
   if (rci) return rci;
+  s->build_flags = build_flags;
 
   // ---- acceleration structure
   auto t0 = std::chrono::steady_clock::now();
@@ -1013,14 +1014,15 @@ static int reupload(rt_scene* s, size_t field, const std::vector<T>& v) {
 }
 #define RT_FIELD(f) offsetof(SceneDev, f)
 
-static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
+// *rebuild: the description is the same shape tree but the hierarchy cannot keep its shape (nothing was changed).
+// *touched: device tables have been written (a failure from here on leaves the scene half updated).
+static int scene_update_impl(rt_scene* s, const rt_scene_desc* d, bool* rebuild, bool* touched) {
   rt_scene::Host& H = s->host;
   // ---- the shape tree must be the one the scene was built from
   if (d->n_leaves != (int32_t)H.leaves.size() || d->n_gates != (int32_t)H.gate_parent.size() || d->n_xforms != H.n_xforms ||
-      d->n_triangles != H.n_triangles || d->n_materials != H.n_materials || d->n_patterns != H.n_patterns ||
-      d->n_chain_mats != H.n_chain_mats || d->n_csg != H.n_csg)
+      d->n_triangles != H.n_triangles || d->n_materials != H.n_materials || d->n_patterns != H.n_patterns || d->n_csg != H.n_csg)
     return fail(RT_ERR_INVALID, "rt_scene_update: the description has other counts than the scene was built from");
-  if (H.n_csg > 0) return fail(RT_ERR_UNSUPPORTED, "rt_scene_update: scenes with CSG operators are rebuilt, not updated");
+  if (d->n_chain_mats < 0 || (d->n_chain_mats > 0 && !d->chain_mats)) return fail(RT_ERR_INVALID, "bad transform chain list");
   if ((d->n_leaves > 0 && !d->leaves) || (d->n_gates > 0 && !d->gates) || (d->n_xforms > 0 && !d->xforms) ||
       (d->n_triangles > 0 && !d->triangles) || (d->n_materials > 0 && !d->materials) || (d->n_patterns > 0 && !d->patterns) ||
       (d->n_chain_mats > 0 && !d->chain_mats))
@@ -1041,14 +1043,20 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
       return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) shape transform: last row must be 0 0 0 1");
   for (int i = 0; i < d->n_chain_mats; i++)
     if (!affine(d->chain_mats + 16 * (size_t)i)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) matrix in a transform chain");
+  if (d->n_chain_mats != H.n_chain_mats) {  // some chain changed its length
+    *rebuild = true;
+    return RT_OK;
+  }
   for (int pass = 0; pass < 2; pass++) {  // the chains keep their places (their matrices may change)
     const rt_chain_ref* now = pass ? d->gate_chain : d->xform_chain;
     const std::vector<rt_chain_ref>& then = pass ? H.gate_chain : H.xform_chain;
     const int n = pass ? d->n_gates : d->n_xforms;
     for (int i = 0; i < n; i++) {
       const rt_chain_ref a = now ? now[i] : rt_chain_ref{0, 0}, b = then.empty() ? rt_chain_ref{0, 0} : then[(size_t)i];
-      if (a.count != b.count || (a.count > 0 && a.first != b.first))
-        return fail(RT_ERR_UNSUPPORTED, "rt_scene_update: a transform chain changed its length (an identity level became a transform or the reverse): rebuild the scene");
+      if (a.count != b.count || (a.count > 0 && a.first != b.first)) {
+        *rebuild = true;  // an identity level became a transform or the reverse: the chains are laid out anew
+        return RT_OK;
+      }
     }
   }
   for (int i = 0; i < d->n_patterns; i++) {
@@ -1062,6 +1070,10 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
     if (d->materials[i].pattern < -1 || d->materials[i].pattern >= d->n_patterns)
       return fail(RT_ERR_INVALID, "material pattern index out of range");
 
+  if (H.n_csg > 0) {  // the operators' records and boxes are laid out by the build
+    *rebuild = true;
+    return RT_OK;
+  }
   SceneBuild b;
   b.d = d;
   // ---- every shape stays where it is: in the hierarchy, or among the shapes tested for every ray
@@ -1077,9 +1089,10 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
   for (int li = 0; li < d->n_leaves; li++) {
     if (d->leaves[li].type == RT_EMPTY) continue;
     double lo[3], hi[3];
-    if (box_of_leaf(li, lo, hi) != (H.boxed[(size_t)li] != 0))
-      return fail(RT_ERR_UNSUPPORTED, "rt_scene_update: a shape crossed between the hierarchy and the shapes tested for every ray "
-                                      "(it became unbounded, or bounded): rebuild the scene");
+    if (d->leaves[li].csg < 0 && box_of_leaf(li, lo, hi) != (H.boxed[(size_t)li] != 0)) {
+      *rebuild = true;  // a shape crossed between the hierarchy and the shapes tested for every ray
+      return RT_OK;
+    }
   }
   for (size_t i = 0; i < tris.size(); i++) {
     const int li = H.tris[i].leaf;
@@ -1123,6 +1136,7 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
   int rc = collect_all(s);
   if (rc) return rc;
   for (hipStream_t st : {s->stream, s->frame_stream[0], s->frame_stream[1], s->frame_stream[2], s->copy_stream}) HIP_TRY(hipStreamSynchronize(st));
+  *touched = true;
   if ((rc = reupload(s, RT_FIELD(tris), tris))) return rc;
   if ((rc = reupload(s, RT_FIELD(quads), quads))) return rc;
   if ((rc = reupload(s, RT_FIELD(gates), gates))) return rc;
@@ -1217,16 +1231,69 @@ static int scene_update_impl(rt_scene* s, const rt_scene_desc* d) {
 }
 #undef RT_FIELD
 
+// The acceleration structure built again from desc for a scene that keeps its handle, streams and frame buffers:
+// a new scene is created beside the old one and the two trade their scene data, so a failure leaves the old
+// scene as it was.
+static int scene_rebuild(rt_scene* s, const rt_scene_desc* d) {
+  rt_scene* fresh = nullptr;
+  int rc = rt_scene_create_with(d, s->device, s->build_flags, &fresh);
+  if (rc != RT_OK) return rc;
+  rc = collect_all(s);
+  if (rc == RT_OK)
+    for (hipStream_t st : {s->stream, s->frame_stream[0], s->frame_stream[1], s->frame_stream[2], s->copy_stream})
+      if (hipStreamSynchronize(st) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_scene_update: a stream of the scene failed");
+  if (rc != RT_OK) {
+    std::string keep = last_error_text();
+    rt_scene_destroy(fresh);
+    last_error_text() = keep;
+    return rc;
+  }
+  std::swap(s->dev, fresh->dev);
+  std::swap(s->allocs, fresh->allocs);
+  std::swap(s->scene_bytes, fresh->scene_bytes);
+  std::swap(s->stack_need, fresh->stack_need);
+  std::swap(s->has_csg, fresh->has_csg);
+  std::swap(s->uniform_nodes, fresh->uniform_nodes);
+  std::swap(s->tri_prefetch, fresh->tri_prefetch);
+  std::swap(s->max_children, fresh->max_children);
+  std::swap(s->set_aside, fresh->set_aside);
+  std::swap(s->host, fresh->host);  // the refit's device arrays travel with their owner
+  s->build_seconds += fresh->build_seconds;
+  s->device_build_seconds += fresh->device_build_seconds;
+  s->device_builds += fresh->device_builds;
+  s->hint_valid = false;
+  s->rebuilds++;
+  rt_scene_destroy(fresh);  // the old tables
+  return RT_OK;
+}
+
 extern "C" int rt_scene_update(rt_scene* s, const rt_scene_desc* desc) {
   if (!s || !desc) return fail(RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(s->device));
+  bool rebuild = false, touched = false;
+  int rc;
   try {
-    return scene_update_impl(s, desc);
+    rc = scene_update_impl(s, desc, &rebuild, &touched);
+    // Shape::set_transform works for any shape (src/shape.rs:592-656).  Where the hierarchy cannot keep its shape --
+    // a shape crossed between bounded and unbounded, a transform chain changed its length, the scene has CSG
+    // operators -- it is built again.
+    if (rc == RT_OK && rebuild) rc = scene_rebuild(s, desc);
   } catch (const std::bad_alloc&) {
-    return fail(RT_ERR_NOMEM, "out of host memory while updating the scene");
+    rc = fail(RT_ERR_NOMEM, "out of host memory while updating the scene");
+  } catch (const std::length_error& e) {
+    rc = fail(RT_ERR_UNSUPPORTED, e.what());
   } catch (const std::exception& e) {
-    return fail(RT_ERR_INVALID, e.what());
+    rc = fail(RT_ERR_INVALID, e.what());
   }
+  if (rc == RT_OK) s->broken = false;
+  else if (touched) s->broken = true;  // some tables are new, some old
+  return rc;
+}
+
+extern "C" int rt_scene_rebuilds(const rt_scene* s, uint64_t* rebuilds) {
+  if (!s || !rebuilds) return fail(RT_ERR_INVALID, "null argument");
+  *rebuilds = s->rebuilds;
+  return RT_OK;
 }
 
 // A second copy of a scene on another GPU (or the same one): the acceleration structure is built once
@@ -1234,6 +1301,7 @@ extern "C" int rt_scene_update(rt_scene* s, const rt_scene_desc* desc) {
 extern "C" int rt_scene_clone(const rt_scene* src, int device, rt_scene** out) {
   if (!src || !out) return fail(RT_ERR_INVALID, "null argument");
   *out = nullptr;
+  RT_REQUIRE_USABLE(src);
   rt_scene* s = new (std::nothrow) rt_scene();
   if (!s) return fail(RT_ERR_NOMEM, "out of host memory");
   auto work = [&]() -> int {
@@ -1256,6 +1324,7 @@ extern "C" int rt_scene_clone(const rt_scene* src, int device, rt_scene** out) {
     s->uniform_nodes = src->uniform_nodes;
     s->tri_prefetch = src->tri_prefetch;
     s->set_aside = src->set_aside;
+    s->build_flags = src->build_flags;
     s->max_children = src->max_children;
     s->host = src->host;  // vectors copied; the refit's device arrays are made on the first update
     s->host.d_tri_box = s->host.d_quad_box = nullptr;

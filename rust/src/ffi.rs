@@ -113,6 +113,7 @@ extern "C" {
     pub fn rt_scene_create_with(desc: *const rt_scene_desc, device: c_int, build_flags: u32, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_build_info(scene: *const rt_scene, device_builds: *mut u64, device_build_seconds: *mut f64) -> c_int;
     pub fn rt_scene_update(scene: *mut rt_scene, desc: *const rt_scene_desc) -> c_int;
+    pub fn rt_scene_rebuilds(scene: *const rt_scene, rebuilds: *mut u64) -> c_int;
     pub fn rt_scene_clone(scene: *const rt_scene, device: c_int, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_footprint(scene: *const rt_scene, scene_bytes: *mut u64, build_seconds: *mut f64) -> c_int;
     pub fn rt_render(scene: *mut rt_scene, camera: *const rt_camera, part: c_int, n_parts: c_int, flags: u32,

@@ -123,4 +123,27 @@ def test_bench_under_the_launcher_assembles_the_same_frame(root):
     assert two["frame_sha256"] == one["frame_sha256"]
     assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
     assert "no collective" in two["config"]["parallelism"]
+    # the whole frame lies in one host buffer when the clock stops (the reference fills one canvas, src/parallel.rs:186)
+    assert two["config"]["frame_assembled_in_timed_region"] is True
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt_amd_bench_")]
+
+
+def test_bench_with_one_loop_per_rank_says_that_the_frame_is_not_assembled(root):
+    """--per-rank-loops: every rank renders and copies its own part into host memory of its own; the ranks' bands are
+    put together after the timed region only, for the checksum, and the line must say so."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    one = run_bench(root, "--gpus", "1", "--steps", "3", "--warmup", "1")
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-hbm-leg", "--no-dealt-leg", "--per-rank-loops"],
+                         capture_output=True, text=True, timeout=400, env=env)
+    assert out.returncode == 0, "\n".join(l for l in out.stderr.splitlines() if l.startswith("[rank"))[-3000:]
+    two = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert two["frame_sha256"] == one["frame_sha256"]
+    assert two["config"]["frame_assembled_in_timed_region"] is False and "not assembled" in two["metric"]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt_amd_bench_")]

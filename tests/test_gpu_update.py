@@ -95,18 +95,66 @@ def test_a_field_of_primitives_moves(pkg, tmp_path):
     check_moves(pkg, scene, [frame, frame[:20]])
 
 
-def test_updates_that_need_a_rebuild_are_refused(pkg):
+def rebuilds(pkg, scene):
+    import ctypes as C
+    amd, _ = pkg.bindings.libraries()
+    amd.rt_scene_rebuilds.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    n = C.c_uint64()
+    assert amd.rt_scene_rebuilds(scene._dev(), C.byref(n)) == 0
+    return n.value
+
+
+def check_against_oracle(got, st, text):
+    ref = orc.OracleScene(text, ROOT).render(jobs=8)
+    assert np.array_equal(got["hit_leaf"], ref["hit_leaf"])
+    assert np.abs(got["rgb64"] - ref["rgb64"]).max() <= 1e-9
+    assert np.array_equal(got["rgb8"], orc.quantise(ref["rgb64"]))
+    assert [st.primary, st.shadow, st.reflect, st.refract] == ref["counts"]
+
+
+def test_updates_the_hierarchy_cannot_follow_build_it_again(pkg):
+    """Shape::set_transform works on any shape (src/shape.rs:592-656).  Where a refit is not enough -- a shape that
+    crosses between the hierarchy and the shapes tested for every ray, a transform chain that changes its length,
+    a scene with CSG operators -- rt_scene_update builds the acceleration structure again; the scene keeps its
+    handle and renders what the oracle renders for the moved world."""
     with open(os.path.join(GOLDEN, "allprims.json")) as f:
         scene = json.load(f)
     s = pkg.Scene(json.dumps(scene), ROOT, device=0)
-    before, _ = s.render()
-    s.set_transform([1], scaling(150, 150, 150))  # a cube that large is tested for every ray, not through the hierarchy
-    with pytest.raises(pkg.bindings.RtError) as e:
-        s.update()
-    assert e.value.status == -2 and "rebuild" in e.value.message
+    s.render()
+    assert rebuilds(pkg, s) == 0
+    big = scaling(150, 150, 150)  # a cube that large is tested for every ray, not through the hierarchy
+    s.set_transform([1], big)
+    s.update()
+    assert rebuilds(pkg, s) == 1
+    scene["shapes"][1]["transform"] = list(big)
+    got, st = s.render()
+    check_against_oracle(got, st, json.dumps(scene))
+    small = matmul(translation(-3.5, 0.4, 1.0), scaling(0.7, 1.2, 0.5))  # and back into the hierarchy
+    s.set_transform([1], small)
+    s.update()
+    assert rebuilds(pkg, s) == 2
+    scene["shapes"][1]["transform"] = list(small)
+    got, st = s.render()
+    check_against_oracle(got, st, json.dumps(scene))
+    # a group two levels down gets a transform of its own where it had none: its shapes' chains grow by one matrix
+    s.set_transform([11, 1], translation(0.0, 0.0, 0.0))
+    s.update()
+    s.set_transform([11, 1], matmul(translation(1.0, 0.3, 0), scaling(0.8, 0.5, 0.8)))
+    s.update()
+    scene["shapes"][11]["children"][1]["transform"] = list(matmul(translation(1.0, 0.3, 0), scaling(0.8, 0.5, 0.8)))
+    got, st = s.render()
+    check_against_oracle(got, st, json.dumps(scene))
+    # scenes with CSG operators
     with open(os.path.join(GOLDEN, "csg.json")) as f:
-        csg = pkg.Scene(f.read(), ROOT, device=0)
-    csg.set_transform([1], translation(0, 1, 0))
-    with pytest.raises(pkg.bindings.RtError) as e:
-        csg.update()
-    assert e.value.status == -2
+        csg_scene = json.load(f)
+    csg = pkg.Scene(json.dumps(csg_scene), ROOT, device=0)
+    csg.render()
+    moved = matmul(translation(0.3, 1.0, -0.2), rot_y(0.5))
+    base = csg_scene["shapes"][1].get("transform")
+    m = matmul(moved, base) if base else moved
+    csg.set_transform([1], m)
+    csg.update()
+    assert rebuilds(pkg, csg) == 1
+    csg_scene["shapes"][1]["transform"] = list(m)
+    got, st = csg.render()
+    check_against_oracle(got, st, json.dumps(csg_scene))
