@@ -341,7 +341,10 @@ int rt_render_host(rt_scene* scene, const rt_camera* camera, int part, int n_par
 int rt_ray_for_pixel(rt_scene* scene, const rt_camera* camera, uint64_t n, const uint32_t* xy,
                      double* rays6);
 
-/* `World::color_at(ray, remaining)` for n rays built with `Ray4D::new`.
+/* `World::color_at(ray, remaining)` for n rays built with `Ray4D::new`, for any remaining >= 0 as in the
+ * reference (src/world.rs:249; the renderer uses 5): every level of the recursion is one generation of rays
+ * whose records stay in HBM until the colours have flowed back, so a deep recursion in a hall of mirrors costs
+ * memory in proportion.  More than 4096 levels are refused (RT_ERR_UNSUPPORTED).
  * rgb = n x 3 doubles; leaf (nullable) = hit leaf index or -1.  Host buffers. */
 int rt_color_at(rt_scene* scene, uint64_t n, const double* rays6, int remaining, uint32_t flags,
                 double* rgb, int32_t* leaf, rt_stats* stats);

@@ -362,7 +362,9 @@ extern "C" int rt_color_at(rt_scene* s, uint64_t n, const double* rays6, int rem
                            int32_t* leaf, rt_stats* stats) {
   if (!s || (n && (!rays6 || !rgb))) return fail(RT_ERR_INVALID, "null argument");
   if (remaining < 0) return fail(RT_ERR_INVALID, "remaining must be >= 0");
-  if (remaining > RECURSION_DEPTH) return fail(RT_ERR_UNSUPPORTED, "remaining above the reference's depth of 5");
+  // any depth, as World::color_at takes any usize (src/world.rs:249); every level keeps its rays' records until the
+  // colours have flowed back, so the depth is bounded by what the host will hold tables for
+  if (remaining > 4096) return fail(RT_ERR_UNSUPPORTED, "remaining above 4096");
   RT_REQUIRE_USABLE(s);
   HIP_TRY(hipSetDevice(s->device));
   if (stats) memset(stats, 0, sizeof(*stats));

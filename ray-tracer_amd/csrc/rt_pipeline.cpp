@@ -9,6 +9,25 @@
 
 using namespace rt;
 
+int rt::ensure_depth(rt_scene* s, int depth) {
+  if (depth <= s->depth && !s->gens.empty()) return RT_OK;
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
+  if (s->d_counts) HIP_TRY(hipFree(s->d_counts));
+  s->d_counts = nullptr;
+  if (s->h_counts) HIP_TRY(hipHostFree(s->h_counts));
+  s->h_counts = nullptr;
+  HIP_TRY(hipMalloc((void**)&s->d_counts, 2 * count_words(depth) * sizeof(uint32_t)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_counts, count_words(depth) * sizeof(uint32_t), hipHostMallocDefault));
+  s->gens.resize((size_t)depth + 2);
+  s->hint.assign((size_t)depth + 3, 0u);
+  s->hint_valid = false;
+  const size_t had = s->ev.size();
+  s->ev.resize(2 * ((size_t)depth + 1), nullptr);
+  for (size_t k = had; k < s->ev.size(); k++) HIP_TRY(hipEventCreate(&s->ev[k]));
+  s->depth = depth;
+  return RT_OK;
+}
+
 int rt::ensure_gen(rt_scene* s, int g, size_t cap) {
   GenBuf& b = s->gens[g];
   if (cap == 0) cap = 64;
@@ -206,8 +225,9 @@ static inline uint64_t safe_segcap(uint64_t n, uint32_t max_children) {
 }
 
 struct GenPlan {
-  uint32_t threads[MAX_GENERATIONS + 2] = {0};  // grid size of generation g (for g > 0 an upper bound when speculative)
-  uint32_t segcap[MAX_GENERATIONS + 2] = {0};   // record slots per queue segment of generation g (g > 0)
+  std::vector<uint32_t> threads;  // grid size of generation g (for g > 0 an upper bound when speculative)
+  std::vector<uint32_t> segcap;   // record slots per queue segment of generation g (g > 0)
+  explicit GenPlan(int depth) : threads((size_t)depth + 3, 0u), segcap((size_t)depth + 3, 0u) {}
 };
 
 static void fill_launch(rt_scene* s, const PipelineIn& in, const GenPlan& plan, int g, int max_gen, GenLaunch& a) {
@@ -227,7 +247,7 @@ static void fill_launch(rt_scene* s, const PipelineIn& in, const GenPlan& plan, 
   a.segcap = plan.segcap[g];
   if (s->set_aside) {  // room was made by ensure_aside(plan.threads[g])
     a.aside = s->aside_buf.view;
-    a.aside.counts = s->d_counts + COUNT_WORDS + g * QUEUE_SEGMENTS;
+    a.aside.counts = s->d_counts + count_words(s->depth) + g * QUEUE_SEGMENTS;
     a.aside.segcap = aside_segcap(plan.threads[g]);
   }
 }
@@ -261,7 +281,7 @@ static int plan_speculative(rt_scene* s, const PipelineIn& in, int max_gen, GenP
     last = g;
   }
   int rc;
-  for (int g = 0; g <= last + 1 && g <= MAX_GENERATIONS; g++)
+  for (int g = 0; g <= last + 1 && g <= s->depth + 1; g++)
     if ((rc = ensure_gen(s, g, g == 0 ? in.n0 : (size_t)plan.segcap[g] * QUEUE_SEGMENTS))) return rc;
   if (s->set_aside) {
     uint32_t most = 0;
@@ -273,7 +293,7 @@ static int plan_speculative(rt_scene* s, const PipelineIn& in, int max_gen, GenP
 }
 
 static int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_stats* stats, bool* fits) {
-  GenPlan plan;
+  GenPlan plan(s->depth);
   int last = 0, rc;
   if ((rc = plan_speculative(s, in, max_gen, plan, &last))) return rc;
   HIP_TRY(hipEventRecord(s->ev[0], main_stream(s)));
@@ -285,7 +305,7 @@ static int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_st
   HIP_TRY(hipEventRecord(s->ev[1], main_stream(s)));
   launch_resolves(s, in, plan, last);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, COUNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, main_stream(s)));
+  HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, count_words(s->depth) * sizeof(uint32_t), hipMemcpyDeviceToHost, main_stream(s)));
   HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                          main_stream(s)));
   HIP_TRY(hipStreamSynchronize(main_stream(s)));
@@ -299,7 +319,7 @@ static int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_st
     true_last = g;
   }
   if (!*fits) return RT_OK;
-  for (int g = 1; g <= MAX_GENERATIONS + 1; g++) {
+  for (int g = 1; g <= s->depth + 2; g++) {
     uint32_t fullest = 0;
     if (g <= true_last)
       for (int k = 0; k < QUEUE_SEGMENTS; k++) fullest = std::max(fullest, s->h_counts[(g - 1) * QUEUE_SEGMENTS + k]);
@@ -320,8 +340,12 @@ static int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_st
 // rays, writes the image.  Fills the device-side fields of stats.
 int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
   const bool count = (in.flags & RT_FLAG_COUNTERS) != 0;
-  int max_gen = std::min(std::max(in.remaining0, 0), RECURSION_DEPTH);
+  int max_gen = std::max(in.remaining0, 0);  // World::color_at recurses `remaining` levels (src/world.rs:146, 185, 249)
   if (s->max_children == 0) max_gen = 0;
+  {
+    int rcd = ensure_depth(s, std::max(max_gen, RECURSION_DEPTH));
+    if (rcd) return rcd;
+  }
   const bool direct = in.camera && max_gen == 0;  // every pixel is final after generation 0
   static const bool no_speculation = getenv("RT_AMD_NO_SPECULATION") != nullptr;
   const bool hinted = max_gen > 0 && !count && !no_speculation && s->hint_valid && s->hint_key[0] == in.n0 &&
@@ -330,7 +354,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     s->holdoff--;
   } else if (hinted) {
     HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
-    HIP_TRY(hipMemsetAsync(s->d_counts, 0, ALL_COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
+    HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * count_words(s->depth) * sizeof(uint32_t), main_stream(s)));
     bool fits = false;
     int rc = run_speculative(s, in, max_gen, stats, &fits);
     if (rc) return rc;
@@ -346,9 +370,9 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     if (debug) fprintf(stderr, "[rt_amd] speculative frame did not fit; exact for the next %u frames\n", s->holdoff);
   }
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
-  if (max_gen > 0 || s->set_aside) HIP_TRY(hipMemsetAsync(s->d_counts, 0, ALL_COUNT_WORDS * sizeof(uint32_t), main_stream(s)));
-  GenPlan plan;
-  uint32_t fullest[MAX_GENERATIONS + 2] = {0};
+  if (max_gen > 0 || s->set_aside) HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * count_words(s->depth) * sizeof(uint32_t), main_stream(s)));
+  GenPlan plan(s->depth);
+  std::vector<uint32_t> fullest((size_t)s->depth + 3, 0u);
   plan.threads[0] = in.n0;
   int last = 0;
   for (int g = 0; g <= max_gen && plan.threads[g] > 0; g++) {
@@ -405,12 +429,12 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
                          main_stream(s)));
   HIP_TRY(hipStreamSynchronize(main_stream(s)));
   if (max_gen > 0) {
-    for (int g = 0; g <= MAX_GENERATIONS + 1; g++) s->hint[g] = fullest[g];
+    for (int g = 0; g <= s->depth + 2; g++) s->hint[(size_t)g] = fullest[(size_t)g];
     s->hint_key[0] = in.n0;
     s->hint_key[1] = (uint32_t)in.remaining0;
     s->hint_valid = true;
     if (!count && !no_speculation) {  // room for the next frame's queues now, not inside that frame
-      GenPlan next_plan;
+      GenPlan next_plan(s->depth);
       int next_last = 0, rc;
       if ((rc = plan_speculative(s, in, max_gen, next_plan, &next_last))) return rc;
     }

@@ -75,8 +75,9 @@ DEV uint32_t thread_in_block() { return (uint32_t)__lane_id(); }
 // adds do not all land on one address.
 constexpr int STAT_SLOTS = 64;
 constexpr int QUEUE_SEGMENTS = 64;
-constexpr int COUNT_WORDS = (MAX_GENERATIONS + 1) * QUEUE_SEGMENTS;  // ray queue counters of one frame
-constexpr int ALL_COUNT_WORDS = 2 * COUNT_WORDS;  // ... then those of the shadow queries set aside
+// Queue counters of one frame for a recursion `depth` deep (generations 0 .. depth, one block of QUEUE_SEGMENTS
+// words per generation and one to spare): the ray queues', then as many for the shadow queries set aside.
+constexpr size_t count_words(int depth) { return (size_t)(depth + 2) * QUEUE_SEGMENTS; }
 constexpr int STAT_RAYS = 8;
 #ifdef RT_STAMPS
 // Diagnostic build: per-wave clock stamps between the sections of k_generation, summed per section.

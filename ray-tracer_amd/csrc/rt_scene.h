@@ -104,14 +104,18 @@ struct rt_scene {
   bool broken = false;
   // queue lengths per generation of the last multi-generation frame: the next frame is launched on them
   // without asking the device after every generation
-  uint32_t hint[rt::MAX_GENERATIONS + 2] = {0};  // [g]: the fullest queue segment of generation g
+  std::vector<uint32_t> hint;                // [g]: the fullest queue segment of generation g (depth + 3 entries)
   uint32_t hint_key[2] = {0, 0};             // n0 and remaining0 the hints belong to
   bool hint_valid = false;
   uint32_t holdoff = 0, holdoff_next = 1;  // frames to render exactly after a speculative frame did not fit
   bool uniform_nodes = false;  // large hierarchy: kernels with the scalar path for nodes a whole wave visits
   bool tri_prefetch = false;   // large mesh: kernels that fetch the next triangle of a run while one is tested
   int max_children = 0;  // rays a hit can spawn: reflective? + transparent?
-  rt::GenBuf gens[rt::MAX_GENERATIONS + 1];
+  // What depends on the recursion depth (rt_color_at takes any `remaining`, src/world.rs:249): the generations'
+  // record buffers (depth + 2), their queue counters, the events around their kernels.  Made for the reference's
+  // depth of 5 (src/consts.rs:10) and grown by ensure_depth() when a caller asks for more.
+  int depth = 0;
+  std::vector<rt::GenBuf> gens;
   // Shadow queries of hits on a cone's extension, walked by a kernel of their own (scenes with bounded cones)
   bool set_aside = false;
   rt::ShadowBuf aside_buf;
@@ -123,7 +127,7 @@ struct rt_scene {
   size_t tiles_capacity = 0;
   std::vector<uint32_t> h_tiles;
   uint32_t tiles_key[4] = {0, 0, 0, 0};  // hsize, vsize, part, n_parts of the uploaded tile table
-  hipEvent_t ev[2 * rt::MAX_GENERATIONS] = {};
+  std::vector<hipEvent_t> ev;  // two per generation
   // frames enqueued under RT_FLAG_ASYNC and not collected yet: a small ring, each slot with its own
   // statistics block so consecutive frames do not share counters
   struct FrameSlot {
@@ -184,6 +188,7 @@ void world_normal(const double* full_inv, const double* local_normal, double* ou
 // rt_pipeline.cpp
 int collect_all(rt_scene* s);  // waits for the frames in flight, then reads and clears the counters they added to
 int ensure_gen(rt_scene* s, int g, size_t cap);
+int ensure_depth(rt_scene* s, int depth);  // buffers, counters and events for a recursion that deep
 int ensure_aside(rt_scene* s, uint32_t rays);  // room for the shadow queries a generation of that many rays may set aside
 int stage_reserve(rt_scene* s, size_t bytes);
 bool affine(const double* m16);  // last row 0 0 0 1

@@ -585,11 +585,9 @@ static int scene_runtime_init(rt_scene* s, int device) {
   HIP_TRY(hipEventCreateWithFlags(&s->copy_order, hipEventDisableTiming));
   for (hipEvent_t& e : s->copy_order2) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (hipEvent_t& e : s->copy_fence) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIP_TRY(hipMalloc((void**)&s->d_counts, ALL_COUNT_WORDS * sizeof(uint32_t)));
   HIP_TRY(hipMalloc((void**)&s->d_stats, STAT_WORDS * sizeof(unsigned long long)));
-  HIP_TRY(hipHostMalloc((void**)&s->h_counts, COUNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&s->h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
-  for (hipEvent_t& e : s->ev) HIP_TRY(hipEventCreate(&e));
+  { int rc = ensure_depth(s, RECURSION_DEPTH); if (rc) return rc; }
   HIP_TRY(hipMalloc((void**)&s->d_async_stats, STAT_WORDS * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->d_async_stats, 0, STAT_WORDS * sizeof(unsigned long long)));
   HIP_TRY(hipHostMalloc((void**)&s->h_async_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));

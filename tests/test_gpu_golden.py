@@ -98,3 +98,40 @@ def test_remaining_limits_the_generations(pkg):
         assert np.abs(rgb - want).max() <= F64_TOL
         assert [st.primary, st.shadow, st.reflect, st.refract] == counts
         assert st.generations <= remaining + 1
+
+
+def test_remaining_beyond_the_renderer_s_depth(pkg):
+    """World::color_at takes any `remaining` (src/world.rs:249); the renderer passes 5.  Rays between two facing
+    mirrors and through nested glass with remaining 6, 9 and 40 against the oracle, then the depth of 5 again on the
+    same scene (the tables grown for the deep calls serve the shallow one)."""
+    import json
+    with open(os.path.join(GOLDEN, "allprims.json")) as f:
+        scene = json.load(f)
+    mirror = {"color": [0.9, 0.9, 1.0], "reflective": 0.9, "diffuse": 0.2, "specular": 0.1}
+    scene["shapes"] += [
+        {"ty": "cube", "transform": [0.05, 0, 0, -4.0, 0, 3, 0, 14.0, 0, 0, 3, 0, 0, 0, 0, 1], "material": mirror},
+        {"ty": "cube", "transform": [0.05, 0, 0, 4.0, 0, 3, 0, 14.0, 0, 0, 3, 0, 0, 0, 0, 1], "material": mirror},
+    ]
+    text = json.dumps(scene)
+    s = pkg.Scene(text, ROOT, device=0)
+    ref = orc.OracleScene(text, ROOT)
+    g = np.load(os.path.join(GOLDEN, "allprims.npz"))
+    rng = np.random.default_rng(2)
+    n = 120
+    o = np.stack([rng.uniform(-3.0, 3.0, n), rng.uniform(12.0, 16.0, n), rng.uniform(-2.0, 2.0, n)], axis=1)
+    d = np.stack([rng.choice([-1.0, 1.0], n), rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n)], axis=1)
+    hall = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1)
+    rays = np.concatenate([hall, g["rays"][:150]])
+    deepest = 0
+    for remaining in (6, 9, 40, 5):
+        rgb, leaf, st = s.color_at(rays, remaining=remaining)
+        want, wleaf, counts = ref.color_at(rays, remaining=remaining)
+        assert np.array_equal(leaf, wleaf)
+        assert np.abs(rgb - want).max() <= F64_TOL
+        assert [st.primary, st.shadow, st.reflect, st.refract] == counts
+        assert st.generations <= remaining + 1
+        deepest = max(deepest, st.generations)
+    assert deepest > 20  # the hall of mirrors really goes that deep
+    with pytest.raises(pkg.RtError) as e:
+        s.color_at(rays[:2], remaining=5000)
+    assert e.value.status == -2

@@ -321,6 +321,47 @@ def test_three_level_csg_of_capped_cylinders(pkg, root):
     assert np.abs(rgb - wrgb).max() <= 1e-9 and [st2.primary, st2.shadow, st2.reflect, st2.refract] == counts
 
 
+def test_csg_of_fifteen_cylinders_in_one_hit_list(pkg, root):
+    """Fifteen overlapping capped cylinders in a row under fourteen operators, left-deep: 60 possible intersections per
+    ray, the longest hit list the kernels hold (46 KB of LDS per wave beside the traversal stack).  Rays along the
+    row cross every cylinder (thirty real intersections in one list); image and rays against the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from scenegen import matmul, rot_x, rot_z, scaling, translation
+
+    ops = ("union", "difference", "union", "union", "union", "union", "difference")
+    tree = None
+    for k in range(15):
+        turn = rot_z(0.15 * (k % 5)) if k % 2 else rot_x(0.1 * (k % 4))
+        c = {"ty": "capped_cylinder", "transform": matmul(translation(0.9 * k - 6.3, 0.1 * (k % 3), 0.05 * (k % 4)), matmul(turn, scaling(0.8, 1.0 + 0.1 * (k % 3), 0.8))),
+             "material": {"color": [0.3 + 0.04 * k, 0.9 - 0.05 * k, 0.5], "reflective": 0.2 if k % 4 == 0 else 0.0}}
+        tree = c if tree is None else {"ty": ops[k % len(ops)], "children": [tree, c]}
+    base = json.load(open(os.path.join(root, "scenes", "example.json")))
+    text = json.dumps(dict(base, canvas_width=192, canvas_height=72, camera_from=[0.0, 2.5, -11.0], camera_to=[0.0, 0.0, 0.0],
+                           shapes=[tree, base["shapes"][1]]))
+    gpu, cpu = pkg.Scene(text, root, device=0), orc.OracleScene(text, root)
+    out, st = gpu.render()
+    want = cpu.render(jobs=8)
+    assert len(np.unique(want["hit_leaf"])) >= 6
+    compare_images(out, st, want, "csg of fifteen capped cylinders")
+    rng = np.random.default_rng(3)
+    n = 600
+    o = np.stack([rng.uniform(-9.5, -8.0, n), rng.uniform(-0.8, 0.9, n), rng.uniform(-0.6, 0.6, n)], axis=1)
+    o[n // 2:, 0] *= -1.0  # half of them from the other end
+    target = np.stack([-o[:, 0], rng.uniform(-0.8, 0.9, n), rng.uniform(-0.6, 0.6, n)], axis=1)
+    d = target - o
+    rays = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1)
+    t, leaf = gpu.intersect_hit(rays)
+    wt, wleaf = cpu.intersect_hit(rays)
+    assert (wleaf >= 0).mean() > 0.5
+    assert np.array_equal(leaf, wleaf)
+    assert np.array_equal(t[leaf >= 0], wt[leaf >= 0])
+    rgb, _, st2 = gpu.color_at(rays)
+    wrgb, _, counts = cpu.color_at(rays)
+    assert np.abs(rgb - wrgb).max() <= 1e-9 and [st2.primary, st2.shadow, st2.reflect, st2.refract] == counts
+    assert np.array_equal(gpu.is_shadowed(rays[:, :3]), cpu.is_shadowed(rays[:, :3]))
+
+
 def test_csg_with_too_many_possible_hits_is_refused(pkg, root):
     cyl = {"ty": "capped_cylinder"}
 
