@@ -1,20 +1,24 @@
-// The acceleration structure built on the GPU: a linear BVH over Morton-sorted item boxes (Karras,
-// "Maximizing parallelism in the construction of BVHs, octrees and k-d trees", 2012), collapsed into
-// the 4-wide nodes the traversal walks (rt_types.h BvhNode).  The host builder (bvh_build.cpp, binned
-// SAH) gives the better tree and stays the default for scenes that are built once; this one is for
-// scenes that are built often or are large: a million triangles in milliseconds.
+// The acceleration structure built on the GPU: parallel locally-ordered clustering over Morton-sorted item
+// boxes (PLOC: Meister and Bittner, "Parallel locally-ordered clustering for bounding volume hierarchy
+// construction", 2018), collapsed into the 4-wide nodes the traversal walks (rt_types.h BvhNode).  The host
+// builder (bvh_build.cpp, binned SAH) stays the default for scenes that are built once; this one is for scenes
+// that are built often or are large: a million triangles in milliseconds.
 //
 //   1. Morton key of every item's box centre (21 bits per axis), radix sort of (key, item)
-//   2. the binary radix tree over the sorted keys: one thread per internal node
-//   3. boxes and the kinds of items below every internal node: unions over its key range, read from a
-//      reduction tree over the sorted leaves (no thread waits for another)
-//   4. where the triangles / quadrics of a range start in the per-kind primitive orders (prefix sums):
-//      a subtree of at most four items of one kind becomes one primitive run
-//   5. the 4-wide nodes, top down, one launch pair per level: a node starts from the two children of a
+//   2. the binary tree, bottom up: the clusters (at first the sorted items) stay in one array; in every round
+//      each cluster looks for the neighbour within PLOC_RADIUS places whose union with it has the smallest
+//      surface, pairs that chose each other merge into a new node, and the array is compacted.  Clusters that
+//      are close in space are close in the array, so the merges follow the surface-area heuristic where a
+//      plain radix tree over the keys (the first version of this builder) splits at bit boundaries: on a
+//      terrain of a million triangles a ray visits a third fewer nodes and triangles.
+//   3. where every item lands in its kind's primitive order: the depth-first order of the tree, found by every
+//      leaf and node walking up to the root and adding up what lies left of its path
+//   4. the 4-wide nodes, top down, one launch pair per level: a node starts from the two children of a
 //      binary node and keeps replacing the child with the largest box by its two children until four
-//      slots are used; the children that are binary nodes themselves become the next level's work.
-//      Node numbers are handed out by a prefix sum over the level, so the build is reproducible.
-//   6. the traversal stack a ray can need, bottom up over the levels
+//      slots are used; a subtree of at most four triangles becomes one primitive run (quadrics stay one per
+//      leaf, as in the host builder); the children that are binary nodes themselves become the next level's
+//      work.  Node numbers are handed out by a prefix sum over the level, so the build is reproducible.
+//   5. the traversal stack a ray can need, bottom up over the levels
 //
 // Any conservative hierarchy over the same leaves returns the same hits (the reference scans every
 // child of a group, src/shape.rs:1213-1219), so images do not depend on which builder ran.
@@ -49,7 +53,7 @@ namespace {
 
 constexpr int THREADS = 256;
 constexpr uint32_t LEAF_BIT = 0x80000000u;  // in a binary child link: the rest is a sorted leaf position
-constexpr uint32_t MAX_RUN_ITEMS = 4;       // items of one kind a primitive run holds at most (as the host builder)
+constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
 
 struct Tree {
   // items, by item id
@@ -60,22 +64,17 @@ struct Tree {
   const int32_t* gate_need; // by gate number: stack entries the subtree behind the gate can need
   uint32_t n_gate_alt, n_gate_need;
   uint32_t n;               // items
+  uint32_t max_run_tris;    // triangles a primitive run holds at most; quadrics stay one per leaf, as in the host builder
   // sorted leaves
-  const unsigned long long* key;
   const uint32_t* item;     // item id at every sorted position
-  const uint32_t* tri_pre;  // triangles before every sorted position (exclusive), n + 1 entries
-  const uint32_t* quad_pre;
-  // binary internal nodes 0 .. n - 2, root 0
-  uint32_t *left, *right, *first, *last, *kmask;
+  uint32_t* leaf_parent;    // binary node above every sorted position
+  uint32_t* leaf_kpos;      // where the item lands in its kind's primitive order
+  // binary internal nodes 0 .. n - 2 in the order they were made, root n - 2
+  uint32_t *left, *right, *parent, *kmask;
+  uint32_t *n_tri, *n_quad;          // triangles / quadrics below
+  uint32_t *tri_first, *quad_first;  // primitive-order position of the first triangle / quadric below
   float* ibox;
 };
-
-__device__ __forceinline__ int delta(const Tree& t, int i, int j) {
-  if (j < 0 || j >= (int)t.n) return -1;
-  const unsigned long long a = t.key[i], b = t.key[j];
-  if (a != b) return __clzll((long long)(a ^ b));
-  return 64 + __clz(i ^ j);  // equal keys: the positions decide
-}
 
 __global__ void __launch_bounds__(THREADS) k_morton(const float* box, uint32_t n, float3 lo, float3 inv_extent, unsigned long long* key,
                                                     uint32_t* item) {
@@ -97,111 +96,142 @@ __global__ void __launch_bounds__(THREADS) k_morton(const float* box, uint32_t n
   item[i] = i;
 }
 
-__global__ void __launch_bounds__(THREADS) k_kind_flags(Tree t, uint32_t* tri_flag, uint32_t* quad_flag) {
-  const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
-  if (i > t.n) return;
-  const uint8_t k = i < t.n ? t.kind[t.item[i]] : 0;
-  tri_flag[i] = k == KIND_TRI ? 1u : 0u;
-  quad_flag[i] = k == KIND_QUAD ? 1u : 0u;
-}
-
-// Step 2 (Karras 2012, figure 4): the range of keys internal node i covers and where it splits.
-__global__ void __launch_bounds__(THREADS) k_radix_tree(Tree t) {
-  const int i = (int)(blockIdx.x * THREADS + threadIdx.x);
-  if (i >= (int)t.n - 1) return;
-  const int d = delta(t, i, i + 1) - delta(t, i, i - 1) >= 0 ? 1 : -1;
-  const int dmin = delta(t, i, i - d);
-  int lmax = 2;
-  while (delta(t, i, i + lmax * d) > dmin) lmax *= 2;
-  int l = 0;
-  for (int step = lmax / 2; step >= 1; step /= 2)
-    if (delta(t, i, i + (l + step) * d) > dmin) l += step;
-  const int j = i + l * d;
-  const int dnode = delta(t, i, j);
-  int s = 0;
-  for (int div = 2;; div *= 2) {
-    const int step = (l + div - 1) / div;
-    if (delta(t, i, i + (s + step) * d) > dnode) s += step;
-    if (step <= 1) break;
-  }
-  const int gamma = i + s * d + min(d, 0);
-  const int lo = min(i, j), hi = max(i, j);
-  const uint32_t left = lo == gamma ? (LEAF_BIT | (uint32_t)gamma) : (uint32_t)gamma;
-  const uint32_t right = hi == gamma + 1 ? (LEAF_BIT | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
-  t.left[i] = left;
-  t.right[i] = right;
-  t.first[i] = (uint32_t)lo;
-  t.last[i] = (uint32_t)hi;
-}
-
 __device__ __forceinline__ uint32_t kind_bit(uint8_t k) { return k == KIND_TRI ? 1u : (k == KIND_QUAD ? 2u : 4u); }
 
-// Step 3.  The box of a binary node is the union of the leaf boxes of its key range.  A complete
-// reduction tree over the sorted leaves (level k holds the unions of 2^k consecutive leaves; one plain
-// launch per level, so no thread waits for another and nothing has to be made visible between compute
-// units inside a launch) answers any range with at most two entries per level.
-struct Seg {  // one entry: box and the kinds of items below
-  float lo[3], hi[3];
-  uint32_t mask;
-};
-__device__ __forceinline__ void seg_join(Seg& a, const Seg& b) {
-  for (int k = 0; k < 3; k++) {
-    a.lo[k] = fminf(a.lo[k], b.lo[k]);
-    a.hi[k] = fmaxf(a.hi[k], b.hi[k]);
-  }
-  a.mask |= b.mask;
-}
-
-__global__ void __launch_bounds__(THREADS) k_seg_leaves(Tree t, Seg* level0) {
+// ---- step 2: the clusters of one round are (link, box) pairs in array order
+__global__ void __launch_bounds__(THREADS) k_ploc_init(Tree t, uint32_t* cid, float* cbox) {
   const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
   if (i >= t.n) return;
-  const uint32_t id = t.item[i];
-  const float* b = t.box + (size_t)id * 6;
-  Seg s;
-  for (int a = 0; a < 3; a++) {
-    s.lo[a] = b[a];
-    s.hi[a] = b[3 + a];
-  }
-  s.mask = kind_bit(t.kind[id]);
-  level0[i] = s;
+  cid[i] = LEAF_BIT | i;
+  const float* b = t.box + (size_t)t.item[i] * 6;
+  for (int a = 0; a < 6; a++) cbox[(size_t)i * 6 + a] = b[a];
+  t.leaf_parent[i] = NO_NODE;
 }
 
-__global__ void __launch_bounds__(THREADS) k_seg_level(const Seg* below, uint32_t n_below, Seg* level, uint32_t n_level) {
-  const uint32_t j = blockIdx.x * THREADS + threadIdx.x;
-  if (j >= n_level) return;
-  Seg s = below[2 * j];
-  if (2 * j + 1 < n_below) seg_join(s, below[2 * j + 1]);
-  level[j] = s;
+// the neighbour whose union with cluster i has the smallest surface; ties go to the lower place
+__global__ void __launch_bounds__(THREADS) k_ploc_nearest(const float* cbox, uint32_t n, uint32_t radius, uint32_t* nn) {
+  const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+  if (i >= n) return;
+  float b[6];
+  for (int a = 0; a < 6; a++) b[a] = cbox[(size_t)i * 6 + a];
+  const uint32_t lo = i > radius ? i - radius : 0u, hi = min(n - 1u, i + radius);
+  float best = INFINITY;
+  uint32_t best_j = i;
+  for (uint32_t j = lo; j <= hi; j++) {
+    if (j == i) continue;
+    const float* c = cbox + (size_t)j * 6;
+    const float dx = fmaxf(b[3], c[3]) - fminf(b[0], c[0]), dy = fmaxf(b[4], c[4]) - fminf(b[1], c[1]),
+                dz = fmaxf(b[5], c[5]) - fminf(b[2], c[2]);
+    const float area = dx * dy + dy * dz + dz * dx;
+    if (area < best) {
+      best = area;
+      best_j = j;
+    }
+  }
+  nn[i] = best_j;
 }
 
-constexpr int SEG_LEVELS = 28;  // 2^27 items at most
-struct SegTree {
-  const Seg* level[SEG_LEVELS];
-};
-
-__global__ void __launch_bounds__(THREADS) k_boxes(Tree t, SegTree seg) {
-  const uint32_t node = blockIdx.x * THREADS + threadIdx.x;
-  if (node + 1 >= t.n) return;
-  uint32_t l = t.first[node], r = t.last[node] + 1u;
-  Seg acc{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}, 0u};
-  for (int k = 0; l < r; k++) {
-    if (l & 1u) seg_join(acc, seg.level[k][l++]);
-    if (r & 1u) seg_join(acc, seg.level[k][--r]);
-    l >>= 1;
-    r >>= 1;
+// per cluster: does it survive the round (high word), does it become a new node (low word); one entry past
+// the end so that the exclusive sums end in the totals
+__global__ void __launch_bounds__(THREADS) k_ploc_flags(const uint32_t* nn, uint32_t n, unsigned long long* flags) {
+  const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    flags[i] = 0ull;
+    return;
   }
-  float* out = t.ibox + (size_t)node * 6;
-  for (int a = 0; a < 3; a++) {
-    out[a] = acc.lo[a];
-    out[3 + a] = acc.hi[a];
-  }
-  t.kmask[node] = acc.mask;
+  const uint32_t j = nn[i];
+  const bool pair = j != i && nn[j] == i;
+  const unsigned long long keep = (pair && j < i) ? 0ull : 1ull, merge = (pair && i < j) ? 1ull : 0ull;
+  flags[i] = (keep << 32) | merge;
 }
 
-// a binary link that ends the 4-wide hierarchy: a leaf, or a subtree that becomes one primitive run
+__device__ __forceinline__ void link_counts(const Tree& t, uint32_t link, uint32_t& tris, uint32_t& quads, uint32_t& mask) {
+  if (link & LEAF_BIT) {
+    const uint8_t k = t.kind[t.item[link & ~LEAF_BIT]];
+    tris = k == KIND_TRI ? 1u : 0u;
+    quads = k == KIND_QUAD ? 1u : 0u;
+    mask = kind_bit(k);
+  } else {
+    tris = t.n_tri[link];
+    quads = t.n_quad[link];
+    mask = t.kmask[link];
+  }
+}
+
+__global__ void __launch_bounds__(THREADS) k_ploc_merge(Tree t, const uint32_t* cid, const float* cbox, const uint32_t* nn,
+                                                        const unsigned long long* offset, uint32_t n, uint32_t first_node,
+                                                        uint32_t* cid_out, float* cbox_out) {
+  const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t j = nn[i];
+  const bool pair = j != i && nn[j] == i;
+  if (pair && j < i) return;  // lives on in its partner
+  const uint32_t place = (uint32_t)(offset[i] >> 32);
+  float b[6];
+  for (int a = 0; a < 6; a++) b[a] = cbox[(size_t)i * 6 + a];
+  uint32_t link = cid[i];
+  if (pair) {
+    const uint32_t node = first_node + (uint32_t)(offset[i] & 0xFFFFFFFFull), other = cid[j];
+    const float* c = cbox + (size_t)j * 6;
+    for (int a = 0; a < 3; a++) {
+      b[a] = fminf(b[a], c[a]);
+      b[3 + a] = fmaxf(b[3 + a], c[3 + a]);
+    }
+    uint32_t lt, lq, lm, rt_, rq, rm;
+    link_counts(t, link, lt, lq, lm);
+    link_counts(t, other, rt_, rq, rm);
+    t.left[node] = link;
+    t.right[node] = other;
+    t.parent[node] = NO_NODE;
+    t.kmask[node] = lm | rm;
+    t.n_tri[node] = lt + rt_;
+    t.n_quad[node] = lq + rq;
+    for (int a = 0; a < 6; a++) t.ibox[(size_t)node * 6 + a] = b[a];
+    if (link & LEAF_BIT) t.leaf_parent[link & ~LEAF_BIT] = node;
+    else t.parent[link] = node;
+    if (other & LEAF_BIT) t.leaf_parent[other & ~LEAF_BIT] = node;
+    else t.parent[other] = node;
+    link = node;
+  }
+  cid_out[place] = link;
+  for (int a = 0; a < 6; a++) cbox_out[(size_t)place * 6 + a] = b[a];
+}
+
+// ---- step 3: depth-first positions.  What precedes a leaf or a subtree in its kind's primitive order is
+// what hangs to the left of its path to the root.
+__global__ void __launch_bounds__(THREADS) k_positions(Tree t, uint32_t* tri_order, uint32_t* quad_order) {
+  const uint32_t x = blockIdx.x * THREADS + threadIdx.x;
+  if (x >= 2u * t.n - 1u) return;
+  const bool leaf = x < t.n;
+  uint32_t link = leaf ? (LEAF_BIT | x) : x - t.n;
+  uint32_t up = leaf ? t.leaf_parent[x] : t.parent[x - t.n];
+  uint32_t tris = 0, quads = 0;
+  while (up != NO_NODE) {
+    if (t.right[up] == link) {
+      uint32_t lt, lq, lm;
+      link_counts(t, t.left[up], lt, lq, lm);
+      tris += lt;
+      quads += lq;
+    }
+    link = up;
+    up = t.parent[up];
+  }
+  if (leaf) {
+    const uint32_t id = t.item[x];
+    const uint8_t k = t.kind[id];
+    t.leaf_kpos[x] = k == KIND_TRI ? tris : quads;
+    if (k == KIND_TRI) tri_order[tris] = t.index[id];
+    else if (k == KIND_QUAD) quad_order[quads] = t.index[id];
+  } else {
+    t.tri_first[x - t.n] = tris;
+    t.quad_first[x - t.n] = quads;
+  }
+}
+
+// a binary link that ends the 4-wide hierarchy: a leaf, or a subtree of triangles that becomes one primitive run
 __device__ __forceinline__ bool is_run_root(const Tree& t, uint32_t inner) {
-  const uint32_t m = t.kmask[inner];
-  return (m == 1u || m == 2u) && t.last[inner] - t.first[inner] + 1u <= MAX_RUN_ITEMS;
+  return t.kmask[inner] == 1u && t.n_tri[inner] <= t.max_run_tris;
 }
 __device__ __forceinline__ bool expandable(const Tree& t, uint32_t link) { return !(link & LEAF_BIT) && !is_run_root(t, link); }
 
@@ -210,21 +240,13 @@ __device__ __forceinline__ const float* link_box(const Tree& t, uint32_t link) {
 }
 
 __device__ uint32_t link_ref(const Tree& t, uint32_t link) {  // for links that are not expandable
-  uint32_t first, count, kmask;
   if (link & LEAF_BIT) {
-    first = link & ~LEAF_BIT;
-    count = 1;
-    const uint32_t id = t.item[first];
+    const uint32_t at = link & ~LEAF_BIT, id = t.item[at];
     const uint8_t k = t.kind[id];
     if (k == KIND_GATE) return (KIND_GATE << 30) | t.index[id];
-    kmask = kind_bit(k);
-  } else {
-    first = t.first[link];
-    count = t.last[link] - first + 1u;
-    kmask = t.kmask[link];
+    return ((uint32_t)k << 30) | t.leaf_kpos[at];  // a run of one
   }
-  return kmask == 1u ? (KIND_TRI << 30) | ((count - 1u) << 27) | t.tri_pre[first]
-                     : (KIND_QUAD << 30) | ((count - 1u) << 27) | t.quad_pre[first];
+  return (KIND_TRI << 30) | ((t.n_tri[link] - 1u) << 27) | t.tri_first[link];
 }
 
 struct Work {
@@ -345,6 +367,20 @@ struct Scan {  // exclusive sums with one reusable workspace
     }
     return hipcub::DeviceScan::ExclusiveSum(tmp, need, in, out, (int)n);
   }
+  hipError_t run64(const unsigned long long* in, unsigned long long* out, size_t n) {
+    size_t need = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n);
+    if (e != hipSuccess) return e;
+    if (need > bytes) {
+      if (tmp) (void)hipFree(tmp);
+      tmp = nullptr;
+      bytes = 0;
+      e = hipMalloc(&tmp, need);
+      if (e != hipSuccess) return e;
+      bytes = need;
+    }
+    return hipcub::DeviceScan::ExclusiveSum(tmp, need, in, out, (int)n);
+  }
   ~Scan() {
     if (tmp) (void)hipFree(tmp);
   }
@@ -380,6 +416,9 @@ int build_bvh_device(const BuildItem* items, size_t n_items, const std::vector<u
   int rc = RT_OK;
   const auto t0 = std::chrono::steady_clock::now();
   static const bool timing = getenv("RT_AMD_BUILD_TIMING") != nullptr;
+  // places to either side a cluster looks for its partner, and the longest triangle run (experiment knobs)
+  const uint32_t radius = getenv("RT_AMD_PLOC_RADIUS") ? (uint32_t)std::max(1, atoi(getenv("RT_AMD_PLOC_RADIUS"))) : 12u;
+  const uint32_t max_run = getenv("RT_AMD_DEVICE_TRI_RUN") ? (uint32_t)std::min(8, std::max(1, atoi(getenv("RT_AMD_DEVICE_TRI_RUN")))) : 4u;
   auto mark = [&, last = t0](const char* what) mutable {
     if (!timing) return;
     (void)hipDeviceSynchronize();
@@ -434,16 +473,16 @@ int build_bvh_device(const BuildItem* items, size_t n_items, const std::vector<u
   const float inv = widest > 0.0f && std::isfinite(widest) ? 1.0f / widest : 0.0f;
   float3 inv_extent = make_float3(inv, inv, inv);
   mark("boxes on the host");
-  float *d_box = nullptr, *d_ibox = nullptr;
+  float *d_box = nullptr, *d_ibox = nullptr, *d_cbox[2] = {nullptr, nullptr};
   uint8_t* d_kind = nullptr;
-  uint32_t *d_index = nullptr, *d_gate_alt = nullptr, *d_item = nullptr, *d_item2 = nullptr, *d_tri_flag = nullptr, *d_quad_flag = nullptr,
-           *d_tri_pre = nullptr, *d_quad_pre = nullptr, *d_left = nullptr, *d_right = nullptr, *d_first = nullptr, *d_last = nullptr,
-           *d_kmask = nullptr, *d_ninner = nullptr, *d_offset = nullptr;
+  uint32_t *d_index = nullptr, *d_gate_alt = nullptr, *d_item = nullptr, *d_item2 = nullptr, *d_left = nullptr, *d_right = nullptr,
+           *d_parent = nullptr, *d_leaf_parent = nullptr, *d_leaf_kpos = nullptr, *d_kmask = nullptr, *d_n_tri = nullptr, *d_n_quad = nullptr,
+           *d_tri_first = nullptr, *d_quad_first = nullptr, *d_cid[2] = {nullptr, nullptr}, *d_nn = nullptr, *d_tri_order = nullptr,
+           *d_quad_order = nullptr, *d_ninner = nullptr, *d_offset = nullptr;
   int32_t *d_gate_need = nullptr, *d_need = nullptr;
-  unsigned long long *d_key = nullptr, *d_key2 = nullptr;
+  unsigned long long *d_key = nullptr, *d_key2 = nullptr, *d_flags = nullptr, *d_sums = nullptr;
   void* d_sort_tmp = nullptr;
   BvhNode* d_nodes = nullptr;
-  Seg* d_seg = nullptr;    // the reduction tree over the sorted leaves: n + n / 2 + ... entries
   Work* d_work = nullptr;  // all levels, one after the other
   uint4* d_slots = nullptr;
   Scan scan;
@@ -464,23 +503,32 @@ int build_bvh_device(const BuildItem* items, size_t n_items, const std::vector<u
     arena.take(&d_key2, n);
     arena.take(&d_item, n);
     arena.take(&d_item2, n);
-    arena.take(&d_tri_flag, (size_t)n + 1);
-    arena.take(&d_quad_flag, (size_t)n + 1);
-    arena.take(&d_tri_pre, (size_t)n + 1);
-    arena.take(&d_quad_pre, (size_t)n + 1);
     arena.take(&d_left, n);
     arena.take(&d_right, n);
-    arena.take(&d_first, n);
-    arena.take(&d_last, n);
+    arena.take(&d_parent, n);
+    arena.take(&d_leaf_parent, n);
+    arena.take(&d_leaf_kpos, n);
     arena.take(&d_kmask, n);
+    arena.take(&d_n_tri, n);
+    arena.take(&d_n_quad, n);
+    arena.take(&d_tri_first, n);
+    arena.take(&d_quad_first, n);
     arena.take(&d_ibox, (size_t)n * 6);
+    for (int k = 0; k < 2; k++) {
+      arena.take(&d_cid[k], n);
+      arena.take(&d_cbox[k], (size_t)n * 6);
+    }
+    arena.take(&d_nn, n);
+    arena.take(&d_flags, (size_t)n + 1);
+    arena.take(&d_sums, (size_t)n + 1);
+    arena.take(&d_tri_order, n);
+    arena.take(&d_quad_order, n);
     arena.take(&d_nodes, n);       // fewer 4-wide nodes than binary ones
     arena.take(&d_work, (size_t)n + 1);
     arena.take(&d_slots, n);
     arena.take(&d_ninner, (size_t)n + 1);
     arena.take(&d_offset, (size_t)n + 1);
     arena.take(&d_need, n);
-    arena.take(&d_seg, 2 * (size_t)n + SEG_LEVELS);
     if (pass == 0) {
       BD_TRY(hipMalloc((void**)&arena.base, arena.used));
       arena.capacity = arena.used;
@@ -506,38 +554,52 @@ int build_bvh_device(const BuildItem* items, size_t n_items, const std::vector<u
     t.gate_alt = d_gate_alt; t.gate_need = d_gate_need;
     t.n_gate_alt = (uint32_t)gate_alt.size(); t.n_gate_need = (uint32_t)h_need.size();
     t.n = n;
-    t.key = d_key2; t.item = d_item2; t.tri_pre = d_tri_pre; t.quad_pre = d_quad_pre;
-    t.left = d_left; t.right = d_right; t.first = d_first; t.last = d_last;
-    t.kmask = d_kmask; t.ibox = d_ibox;
-    // ---- 4 (needs only the order). primitive orders: where every kind's items of a range start
-    hipLaunchKernelGGL(k_kind_flags, grid((size_t)n + 1), block, 0, 0, t, d_tri_flag, d_quad_flag);
-    BD_TRY(scan.run(d_tri_flag, d_tri_pre, (size_t)n + 1));
-    BD_TRY(scan.run(d_quad_flag, d_quad_pre, (size_t)n + 1));
-    // ---- 2, 3. the binary tree and its boxes
-    mark("kind flags, prefix sums");
-    hipLaunchKernelGGL(k_radix_tree, grid(n - 1), block, 0, 0, t);
-    mark("radix tree");
+    t.max_run_tris = max_run;
+    t.item = d_item2; t.leaf_parent = d_leaf_parent; t.leaf_kpos = d_leaf_kpos;
+    t.left = d_left; t.right = d_right; t.parent = d_parent; t.kmask = d_kmask;
+    t.n_tri = d_n_tri; t.n_quad = d_n_quad; t.tri_first = d_tri_first; t.quad_first = d_quad_first;
+    t.ibox = d_ibox;
+    // ---- 2. the binary tree, bottom up
     {
-      SegTree seg{};
-      Seg* base = d_seg;
-      uint32_t n_level = n;
-      hipLaunchKernelGGL(k_seg_leaves, grid(n), block, 0, 0, t, base);
-      seg.level[0] = base;
-      for (int k = 1; k < SEG_LEVELS && n_level > 1; k++) {
-        const uint32_t n_below = n_level;
-        Seg* below = base;
-        base += n_below;
-        n_level = (n_below + 1) / 2;
-        hipLaunchKernelGGL(k_seg_level, grid(n_level), block, 0, 0, (const Seg*)below, n_below, base, n_level);
-        seg.level[k] = base;
+      hipLaunchKernelGGL(k_ploc_init, grid(n), block, 0, 0, t, d_cid[0], d_cbox[0]);
+      uint32_t clusters = n, made = 0;
+      int cur = 0, rounds = 0;
+      while (clusters > 1) {
+        if (++rounds > 4096) {  // every round merges at least the closest pair
+          rc = rt_fail_message(RT_ERR_DEVICE, "device build: the clustering does not end");
+          goto done;
+        }
+        hipLaunchKernelGGL(k_ploc_nearest, grid(clusters), block, 0, 0, (const float*)d_cbox[cur], clusters, radius, d_nn);
+        hipLaunchKernelGGL(k_ploc_flags, grid((size_t)clusters + 1), block, 0, 0, (const uint32_t*)d_nn, clusters, d_flags);
+        BD_TRY(scan.run64(d_flags, d_sums, (size_t)clusters + 1));
+        unsigned long long total = 0;
+        BD_TRY(hipMemcpy(&total, d_sums + clusters, sizeof total, hipMemcpyDeviceToHost));
+        const uint32_t kept = (uint32_t)(total >> 32), merged = (uint32_t)(total & 0xFFFFFFFFull);
+        if (merged == 0 || kept + merged != clusters || made + merged > n - 1) {
+          rc = rt_fail_message(RT_ERR_DEVICE, "device build: inconsistent clustering round");
+          goto done;
+        }
+        hipLaunchKernelGGL(k_ploc_merge, grid(clusters), block, 0, 0, t, (const uint32_t*)d_cid[cur], (const float*)d_cbox[cur],
+                           (const uint32_t*)d_nn, (const unsigned long long*)d_sums, clusters, made, d_cid[cur ^ 1], d_cbox[cur ^ 1]);
+        made += merged;
+        clusters = kept;
+        cur ^= 1;
       }
-      hipLaunchKernelGGL(k_boxes, grid(n - 1), block, 0, 0, t, seg);
+      BD_TRY(hipGetLastError());
+      if (made != n - 1) {
+        rc = rt_fail_message(RT_ERR_DEVICE, "device build: the tree is not complete");
+        goto done;
+      }
+      if (timing) fprintf(stderr, "[rt_amd]   device build: %d clustering rounds\n", rounds);
     }
+    mark("clustering");
+    // ---- 3. depth-first positions and the primitive orders
+    hipLaunchKernelGGL(k_positions, grid(2 * (size_t)n - 1), block, 0, 0, t, d_tri_order, d_quad_order);
     BD_TRY(hipGetLastError());
-    mark("boxes");
-    // ---- 5. the 4-wide nodes, level by level.  The root binary node always becomes node 0: a range of
+    mark("positions");
+    // ---- 4. the 4-wide nodes, level by level.  The root binary node always becomes node 0: a range of
     // two to four items of one kind could be a single run, but then there would be no node to hold its box.
-    const Work root_work{0u, 0u};
+    const Work root_work{n - 2u, 0u};  // the node made last
     BD_TRY(hipMemcpy(d_work, &root_work, sizeof(Work), hipMemcpyHostToDevice));
     uint32_t first = 0, count = 1;
     while (count > 0) {
@@ -563,28 +625,23 @@ int build_bvh_device(const BuildItem* items, size_t n_items, const std::vector<u
       count = next_count;
     }
     mark("collapse to 4-wide nodes");
-    // ---- 6. stack need, deepest level first
+    // ---- 5. stack need, deepest level first
     for (size_t l = level_first.size(); l-- > 0;)
       hipLaunchKernelGGL(k_stack_need, grid(level_count[l]), block, 0, 0, t, (const Work*)(d_work + level_first[l]), level_count[l],
                          (const BvhNode*)d_nodes, d_need);
     BD_TRY(hipGetLastError());
     int32_t root_need = 0;
     BD_TRY(hipMemcpy(&root_need, d_need, 4, hipMemcpyDeviceToHost));
-    BD_TRY(hipMemcpy(totals, d_tri_pre + n, 4, hipMemcpyDeviceToHost));
-    BD_TRY(hipMemcpy(totals + 1, d_quad_pre + n, 4, hipMemcpyDeviceToHost));
+    BD_TRY(hipMemcpy(totals, d_n_tri + (n - 2u), 4, hipMemcpyDeviceToHost));
+    BD_TRY(hipMemcpy(totals + 1, d_n_quad + (n - 2u), 4, hipMemcpyDeviceToHost));
     mark("stack need");
     // ---- results back to the host builder's vectors
     out->nodes.resize(n_nodes);
     BD_TRY(hipMemcpy(out->nodes.data(), d_nodes, (size_t)n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
-    std::vector<uint32_t> order(n);
-    BD_TRY(hipMemcpy(order.data(), d_item2, (size_t)n * 4, hipMemcpyDeviceToHost));
-    out->tri_order.reserve(totals[0]);
-    out->quad_order.reserve(totals[1]);
-    for (uint32_t i = 0; i < n; i++) {
-      const uint32_t id = order[i];
-      if (h_kind[id] == KIND_TRI) out->tri_order.push_back(h_index[id]);
-      else if (h_kind[id] == KIND_QUAD) out->quad_order.push_back(h_index[id]);
-    }
+    out->tri_order.resize(totals[0]);
+    out->quad_order.resize(totals[1]);
+    if (totals[0]) BD_TRY(hipMemcpy(out->tri_order.data(), d_tri_order, (size_t)totals[0] * 4, hipMemcpyDeviceToHost));
+    if (totals[1]) BD_TRY(hipMemcpy(out->quad_order.data(), d_quad_order, (size_t)totals[1] * 4, hipMemcpyDeviceToHost));
     mark("download, primitive orders");
     out->root = make_ref(KIND_INNER, 0);
     out->stack_need = root_need;

@@ -400,7 +400,7 @@ extern "C" int rt_intersect_hit(rt_scene* s, uint64_t n, const double* rays6, do
   if (n == 0) return RT_OK;
   int rc = load_user_rays(s, n, rays6);
   if (rc) return rc;
-  launch_intersect(main_stream(s), s->dev, pick_stack(s->stack_need), s->has_csg, csg_lds_bytes(s), s->gens[0].view, (uint32_t)n);
+  launch_intersect(main_stream(s), s->dev, s->has_csg, traversal_lds_bytes(s), s->gens[0].view, (uint32_t)n);
   double* d_t = (double*)s->stage;
   int32_t* d_leaf = (int32_t*)(d_t + n);
   launch_output_rays(main_stream(s), s->gens[0].view, (uint32_t)n, (double*)nullptr, d_leaf, d_t);
@@ -422,7 +422,7 @@ extern "C" int rt_is_shadowed(rt_scene* s, uint64_t n, const double* points3, ui
   double* d_pts = (double*)s->stage;
   uint8_t* d_out = (uint8_t*)(d_pts + n * 3);
   HIP_TRY(hipMemcpyAsync(d_pts, points3, n * 3 * sizeof(double), hipMemcpyHostToDevice, main_stream(s)));
-  launch_points_shadowed(main_stream(s), s->dev, pick_stack(s->stack_need), s->has_csg, csg_lds_bytes(s), (uint32_t)n, d_pts, d_out);
+  launch_points_shadowed(main_stream(s), s->dev, s->has_csg, traversal_lds_bytes(s), (uint32_t)n, d_pts, d_out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(shadowed, d_out, n, hipMemcpyDeviceToHost, main_stream(s)));
   HIP_TRY(hipStreamSynchronize(main_stream(s)));

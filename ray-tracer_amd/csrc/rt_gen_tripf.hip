@@ -3,5 +3,5 @@
 #include "rt_generation.h"
 
 namespace rt {
-template void launch_generation_variant<40, false, false, false, false>(const SceneDev&, unsigned, int, const GenLaunch&);
+template void launch_generation_variant<false, false, true, true>(const SceneDev&, unsigned, int, const GenLaunch&);
 }  // namespace rt

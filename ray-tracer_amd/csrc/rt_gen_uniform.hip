@@ -3,5 +3,5 @@
 #include "rt_generation.h"
 
 namespace rt {
-template void launch_generation_variant<64, true, false, false, false>(const SceneDev&, unsigned, int, const GenLaunch&);
+template void launch_generation_variant<false, false, true, false>(const SceneDev&, unsigned, int, const GenLaunch&);
 }  // namespace rt

@@ -24,7 +24,7 @@ namespace rt {
 #ifndef RT_MIN_WAVES_SPAWN
 #define RT_MIN_WAVES_SPAWN 3
 #endif
-template <int STACK, bool COUNT, int MODE, bool CSG, bool UNIFORM, bool TRIPF = false>
+template <bool COUNT, int MODE, bool CSG, bool UNIFORM, bool TRIPF = false>
 // Waves per SIMD a kernel is compiled for.  The ray-spawning modes need about 170 registers: at three waves
 // nothing much spills, and small scenes, whose records come from L1, run fastest that way (glass 4K: 0.67 ms
 // against 0.88 at four waves, 0.76 at two).  The kernels for large hierarchies wait on L2 and beyond, and a
@@ -33,10 +33,11 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
     k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_segcap, int remaining,
                  uint32_t* next_counts, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
                  uint32_t tiles_x, ImageOut img, const uint32_t* queue_counts, uint32_t segcap, ShadowView aside) {
-  __shared__ uint32_t lds[STACK * BLOCK];
-  LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF> st;
-  extern __shared__ uint32_t csg_lds[];  // SceneDev::csg_hits * 3 * BLOCK words when the scene has CSG operators, else nothing
-  st.init(lds, CSG ? csg_lds : nullptr);
+  // dynamic LDS: SceneDev::stack_entries * BLOCK words of traversal stack, then SceneDev::csg_hits * 3 * BLOCK words
+  // of CSG hit list when the scene has operators
+  extern __shared__ uint32_t dyn_lds[];
+  LdsStack<BLOCK, CSG, UNIFORM, TRIPF> st;
+  st.init(dyn_lds, S.stack_entries);
 #ifdef RT_STAMPS
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
   ClosestQuery Q;
   Q.init();
   RT_STAMP(0);  // ray generation
-  if (active) traverse<ClosestQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, ray, Q, st, ct);
+  if (active) traverse<ClosestQuery, LdsStack<BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, ray, Q, st, ct);
   RT_STAMP(1);  // closest-hit traversal
   const bool hit = active && Q.best_leaf != 0x7FFFFFFF;
   const int leaf = hit ? Q.best_leaf : -1;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
     if (MODE != 0 && (material->flags & 8)) {  // they are consumed: refraction or Schlick
       ContainerQuery C;
       C.init(leaf);
-      traverse<ContainerQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, ray, C, st, ct);
+      traverse<ContainerQuery, LdsStack<BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, ray, C, st, ct);
       double ri_hit = material->refractive_index;
       double ri_other = C.other_leaf >= 0 ? S.materials[S.leaves[C.other_leaf].material].refractive_index : 1.0;
       if (C.hit_inside) {
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
     SQ.found = false;
     Ray shadow_ray{over_point, lightv};
     if (walk)
-      traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, shadow_ray, SQ, st, cs);
+      traverse<ShadowQuery, LdsStack<BLOCK, CSG, UNIFORM, TRIPF>, COUNT>(S, shadow_ray, SQ, st, cs);
     out_r = SQ.found ? ar : lr;
     out_g = SQ.found ? ag : lg;
     out_b = SQ.found ? ab : lb;
@@ -334,14 +335,13 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
 // (src/world.rs:123-137), then lighting()'s in_shadow branch (src/light.rs:135-141) for the points that
 // are: the ambient colour replaces the lit one the generation kernel stored -- in the ray's record when it
 // has one that is read again (mode 2: every ray; mode 1: camera rays with children), else in its pixel.
-template <int STACK, bool COUNT, bool CSG, bool UNIFORM>
+template <bool COUNT, bool CSG, bool UNIFORM>
 __global__ void __launch_bounds__(BLOCK, RT_MIN_WAVES)
     k_shadow(SceneDev S, ShadowView q, uint32_t n, GenView g, int mode, unsigned long long* stats, CameraDev cam,
              const uint32_t* tiles, uint32_t tiles_x, ImageOut img) {
-  __shared__ uint32_t lds[STACK * BLOCK];
-  LdsStack<STACK, BLOCK, CSG, UNIFORM, false> st;
-  extern __shared__ uint32_t csg_lds[];
-  st.init(lds, CSG ? csg_lds : nullptr);
+  extern __shared__ uint32_t dyn_lds[];
+  LdsStack<BLOCK, CSG, UNIFORM, false> st;
+  st.init(dyn_lds, S.stack_entries);
   const uint32_t i = blockIdx.x * BLOCK + thread_in_block();
   uint32_t slot = 0;
   const bool active = queue_slot(q.counts, q.segcap, i, slot) && i < n;  // n only bounds the grid
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(BLOCK, RT_MIN_WAVES)
     const V3 v = v3(S.light_position[0], S.light_position[1], S.light_position[2]) - p;
     SQ.distance = magnitude(v);
     const Ray shadow_ray{p, normalize(v)};
-    traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG, UNIFORM, false>, COUNT>(S, shadow_ray, SQ, st, cs);
+    traverse<ShadowQuery, LdsStack<BLOCK, CSG, UNIFORM, false>, COUNT>(S, shadow_ray, SQ, st, cs);
   }
   if (active && SQ.found) {
     const uint32_t rec = q.target[slot];
@@ -382,23 +382,23 @@ __global__ void __launch_bounds__(BLOCK, RT_MIN_WAVES)
 // Launches the kernel of one generation for this combination of template arguments, and after it the kernel
 // of the shadow queries it set aside (a.aside.segcap != 0: scenes with bounded cones).  Defined where the
 // kernels are instantiated (rt_gen_*.hip); rt_launch.h declares it for the host pipeline.
-template <int STACK, bool COUNT, bool CSG, bool UNIFORM, bool TRIPF>
-void launch_generation_variant(const SceneDev& dev, unsigned extra_lds, int mode, const GenLaunch& a) {
+template <bool COUNT, bool CSG, bool UNIFORM, bool TRIPF>
+void launch_generation_variant(const SceneDev& dev, unsigned lds_bytes, int mode, const GenLaunch& a) {
   dim3 grid((a.n + BLOCK - 1) / BLOCK), block(BLOCK);
 #define RT_GEN_ARGS dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap, a.aside
   if constexpr (TRIPF) {  // only camera rays of scenes that spawn nothing fetch triangles ahead
-    hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG, UNIFORM, true>), grid, block, extra_lds, a.stream, RT_GEN_ARGS);
+    hipLaunchKernelGGL((k_generation<COUNT, 0, CSG, UNIFORM, true>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS);
   } else {
     switch (mode) {
-      case 0: hipLaunchKernelGGL((k_generation<STACK, COUNT, 0, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
-      case 1: hipLaunchKernelGGL((k_generation<STACK, COUNT, 1, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
-      default: hipLaunchKernelGGL((k_generation<STACK, COUNT, 2, CSG, UNIFORM>), grid, block, extra_lds, a.stream, RT_GEN_ARGS); break;
+      case 0: hipLaunchKernelGGL((k_generation<COUNT, 0, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS); break;
+      case 1: hipLaunchKernelGGL((k_generation<COUNT, 1, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS); break;
+      default: hipLaunchKernelGGL((k_generation<COUNT, 2, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS); break;
     }
   }
 #undef RT_GEN_ARGS
   if (a.aside.segcap != 0u) {  // the grid covers the queue's room; waves beyond its end exit at once
     const uint32_t room = a.aside.segcap * QUEUE_SEGMENTS;
-    hipLaunchKernelGGL((k_shadow<STACK, COUNT, CSG, UNIFORM>), dim3((room + BLOCK - 1) / BLOCK), block, extra_lds, a.stream, dev,
+    hipLaunchKernelGGL((k_shadow<COUNT, CSG, UNIFORM>), dim3((room + BLOCK - 1) / BLOCK), block, lds_bytes, a.stream, dev,
                        a.aside, room, a.cur, mode, a.stats, a.cam, a.tiles, a.tiles_x, a.img);
   }
 }

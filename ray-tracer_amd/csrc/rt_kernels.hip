@@ -99,32 +99,30 @@ __global__ void __launch_bounds__(BLOCK)
 }
 
 // World::intersect + Intersections::hit only (rt_intersect_hit).
-template <int STACK, bool CSG>
+template <bool CSG>
 __global__ void __launch_bounds__(BLOCK) k_intersect(SceneDev S, GenView g, uint32_t n) {
-  __shared__ uint32_t lds[STACK * BLOCK];
+  extern __shared__ uint32_t dyn_lds[];  // traversal stack, then the CSG hit list (see k_generation)
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
-  LdsStack<STACK, BLOCK, CSG> st;
-  extern __shared__ uint32_t csg_lds[];  // SceneDev::csg_hits * 3 * BLOCK words when the scene has CSG operators, else nothing
-  st.init(lds, CSG ? csg_lds : nullptr);
+  LdsStack<BLOCK, CSG> st;
+  st.init(dyn_lds, S.stack_entries);
   Counters cnt{};
   ClosestQuery Q;
   Q.init();
-  traverse<ClosestQuery, LdsStack<STACK, BLOCK, CSG>, false>(S, load_ray(g, i), Q, st, cnt);
+  traverse<ClosestQuery, LdsStack<BLOCK, CSG>, false>(S, load_ray(g, i), Q, st, cnt);
   bool hit = Q.best_leaf != 0x7FFFFFFF;
   g.leaf[i] = hit ? Q.best_leaf : -1;
   if (hit) g.t[i] = Q.best_t;
 }
 
 // World::is_shadowed for caller-supplied points.
-template <int STACK, bool CSG>
+template <bool CSG>
 __global__ void __launch_bounds__(BLOCK) k_points_shadowed(SceneDev S, uint32_t n, const double* pts, uint8_t* out) {
-  __shared__ uint32_t lds[STACK * BLOCK];
+  extern __shared__ uint32_t dyn_lds[];  // traversal stack, then the CSG hit list (see k_generation)
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
-  LdsStack<STACK, BLOCK, CSG> st;
-  extern __shared__ uint32_t csg_lds[];  // SceneDev::csg_hits * 3 * BLOCK words when the scene has CSG operators, else nothing
-  st.init(lds, CSG ? csg_lds : nullptr);
+  LdsStack<BLOCK, CSG> st;
+  st.init(dyn_lds, S.stack_entries);
   Counters cnt{};
   V3 p = v3(pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]);
   V3 v = v3(S.light_position[0], S.light_position[1], S.light_position[2]) - p;
@@ -132,7 +130,7 @@ __global__ void __launch_bounds__(BLOCK) k_points_shadowed(SceneDev S, uint32_t 
   Q.distance = magnitude(v);
   Q.found = false;
   Ray ray{p, normalize(v)};
-  traverse<ShadowQuery, LdsStack<STACK, BLOCK, CSG>, false>(S, ray, Q, st, cnt);
+  traverse<ShadowQuery, LdsStack<BLOCK, CSG>, false>(S, ray, Q, st, cnt);
   out[i] = Q.found ? 1 : 0;
 }
 
@@ -234,16 +232,14 @@ void launch_resolve_pixels(hipStream_t stream, GenView g, uint32_t n, GenView ne
 void launch_output_rays(hipStream_t stream, GenView g, uint32_t n, double* rgb, int32_t* leaf, double* t) {
   hipLaunchKernelGGL(k_output_rays, grid_for(n), dim3(BLOCK), 0, stream, g, n, rgb, leaf, t);
 }
-void launch_intersect(hipStream_t stream, const SceneDev& dev, int stack, bool general, unsigned extra_lds, GenView g, uint32_t n) {
-  if (general) hipLaunchKernelGGL((k_intersect<64, true>), grid_for(n), dim3(BLOCK), extra_lds, stream, dev, g, n);
-  else if (stack == STACK_SMALL) hipLaunchKernelGGL((k_intersect<STACK_SMALL, false>), grid_for(n), dim3(BLOCK), 0, stream, dev, g, n);
-  else hipLaunchKernelGGL((k_intersect<64, false>), grid_for(n), dim3(BLOCK), 0, stream, dev, g, n);
+void launch_intersect(hipStream_t stream, const SceneDev& dev, bool general, unsigned lds_bytes, GenView g, uint32_t n) {
+  if (general) hipLaunchKernelGGL((k_intersect<true>), grid_for(n), dim3(BLOCK), lds_bytes, stream, dev, g, n);
+  else hipLaunchKernelGGL((k_intersect<false>), grid_for(n), dim3(BLOCK), lds_bytes, stream, dev, g, n);
 }
-void launch_points_shadowed(hipStream_t stream, const SceneDev& dev, int stack, bool general, unsigned extra_lds, uint32_t n,
+void launch_points_shadowed(hipStream_t stream, const SceneDev& dev, bool general, unsigned lds_bytes, uint32_t n,
                             const double* pts, uint8_t* out) {
-  if (general) hipLaunchKernelGGL((k_points_shadowed<64, true>), grid_for(n), dim3(BLOCK), extra_lds, stream, dev, n, pts, out);
-  else if (stack == STACK_SMALL) hipLaunchKernelGGL((k_points_shadowed<STACK_SMALL, false>), grid_for(n), dim3(BLOCK), 0, stream, dev, n, pts, out);
-  else hipLaunchKernelGGL((k_points_shadowed<64, false>), grid_for(n), dim3(BLOCK), 0, stream, dev, n, pts, out);
+  if (general) hipLaunchKernelGGL((k_points_shadowed<true>), grid_for(n), dim3(BLOCK), lds_bytes, stream, dev, n, pts, out);
+  else hipLaunchKernelGGL((k_points_shadowed<false>), grid_for(n), dim3(BLOCK), lds_bytes, stream, dev, n, pts, out);
 }
 void launch_pixel_rays(hipStream_t stream, const CameraDev& cam, uint32_t n, const uint32_t* xy, double* rays6) {
   hipLaunchKernelGGL(k_pixel_rays, grid_for(n), dim3(BLOCK), 0, stream, cam, n, xy, rays6);

@@ -74,23 +74,15 @@ namespace {
 // The kernel for this scene and generation: the instantiations live in rt_gen_*.hip.
 void launch_generation(rt_scene* s, int mode, bool count, const GenLaunch& a) {
   static const unsigned env_lds = getenv("RT_AMD_EXTRA_LDS") ? (unsigned)atoi(getenv("RT_AMD_EXTRA_LDS")) : 0u;
-  const unsigned lds = (s->has_csg ? csg_lds_bytes(s) : 0u) + env_lds;
-  const bool small = pick_stack(s->stack_need) == STACK_SMALL;
+  const unsigned lds = traversal_lds_bytes(s) + env_lds;
   const bool tripf = s->uniform_nodes && s->tri_prefetch && mode == 0;
-  if (s->has_csg) {  // scenes with CSG operators or transform chains: the general kernels (64-entry stack)
-    if (count) launch_generation_variant<64, true, true, false, false>(s->dev, lds, mode, a);
-    else launch_generation_variant<64, false, true, false, false>(s->dev, lds, mode, a);
-  } else if (small) {
-    if (count) launch_generation_variant<STACK_SMALL, true, false, false, false>(s->dev, lds, mode, a);
-    else if (tripf) launch_generation_variant<STACK_SMALL, false, false, true, true>(s->dev, lds, mode, a);
-    else if (s->uniform_nodes) launch_generation_variant<STACK_SMALL, false, false, true, false>(s->dev, lds, mode, a);
-    else launch_generation_variant<STACK_SMALL, false, false, false, false>(s->dev, lds, mode, a);
-  } else {
-    if (count) launch_generation_variant<64, true, false, false, false>(s->dev, lds, mode, a);
-    else if (tripf) launch_generation_variant<64, false, false, true, true>(s->dev, lds, mode, a);
-    else if (s->uniform_nodes) launch_generation_variant<64, false, false, true, false>(s->dev, lds, mode, a);
-    else launch_generation_variant<64, false, false, false, false>(s->dev, lds, mode, a);
-  }
+  if (s->has_csg) {  // scenes with CSG operators or transform chains: the general kernels
+    if (count) launch_generation_variant<true, true, false, false>(s->dev, lds, mode, a);
+    else launch_generation_variant<false, true, false, false>(s->dev, lds, mode, a);
+  } else if (count) launch_generation_variant<true, false, false, false>(s->dev, lds, mode, a);
+  else if (tripf) launch_generation_variant<false, false, true, true>(s->dev, lds, mode, a);
+  else if (s->uniform_nodes) launch_generation_variant<false, false, true, false>(s->dev, lds, mode, a);
+  else launch_generation_variant<false, false, false, false>(s->dev, lds, mode, a);
 }
 
 }  // namespace

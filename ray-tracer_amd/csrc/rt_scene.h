@@ -193,8 +193,11 @@ int ensure_aside(rt_scene* s, uint32_t rays);  // room for the shadow queries a 
 int stage_reserve(rt_scene* s, size_t bytes);
 bool affine(const double* m16);  // last row 0 0 0 1
 inline void copy3x4(double* dst, const double* src16) { memcpy(dst, src16, 12 * sizeof(double)); }
-// dynamic LDS of the kernels that evaluate CSG operators: the per-lane hit list
-inline unsigned csg_lds_bytes(const rt_scene* s) { return (unsigned)s->dev.csg_hits * 3u * BLOCK * (unsigned)sizeof(uint32_t); }
+// dynamic LDS of a traversal kernel's workgroup: the per-lane stack, then (scenes with CSG operators) the hit list
+inline unsigned traversal_lds_bytes(const rt_scene* s) {
+  return (unsigned)s->dev.stack_entries * BLOCK * (unsigned)sizeof(uint32_t) +
+         (s->has_csg ? (unsigned)s->dev.csg_hits * 3u * BLOCK * (unsigned)sizeof(uint32_t) : 0u);
+}
 
 struct PipelineIn {
   uint32_t n0 = 0;

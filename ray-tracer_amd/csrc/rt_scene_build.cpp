@@ -747,6 +747,8 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
   s->stack_need = b.bvh.stack_need + 2 + 3;  // + root and gate hand-over, + 3 scratch slots of push_if
   if (s->stack_need > TRAVERSAL_STACK)
     return fail(RT_ERR_UNSUPPORTED, "scene hierarchy is deeper than the traversal stack");
+  // what the kernels are launched with: the need, in steps of four, and room for the cone index's queue
+  s->dev.stack_entries = std::min(TRAVERSAL_STACK, std::max(16, (s->stack_need + 3) & ~3));
   if (getenv("RT_AMD_DEBUG")) {
     fprintf(stderr, "[rt_amd] leaves=%d gates=%d nodes=%zu tris=%zu quads=%zu unbounded=%zu bands=%zu stack_need=%d\n", d->n_leaves,
             d->n_gates, b.bvh.nodes.size(), b.bvh.tri_order.size(), b.bvh.quad_order.size(), b.unbounded.size(), b.bands.size(),

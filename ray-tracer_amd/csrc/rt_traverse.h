@@ -8,28 +8,29 @@
 namespace rt {
 
 // Per-lane stack in LDS: entry e of thread t lives at stack[e * BLOCK + t], so
-// the 64 lanes of a wave hit 64 consecutive banks.
-template <int STACK, int BLOCK, bool CSG = false, bool UNIFORM = false, bool TRIPF = false>
+// the 64 lanes of a wave hit 64 consecutive banks.  The LDS is dynamic: a launch asks for as many entries as
+// the scene's hierarchy can need, so a shallow scene leaves the LDS to more waves and a deep one still fits.
+template <int BLOCK, bool CSG = false, bool UNIFORM = false, bool TRIPF = false>
 struct LdsStack {
   static constexpr bool WITH_CSG = CSG;  // the kernels built for scenes with CSG operators carry eval_csg
   static constexpr bool UNIFORM_NODES = UNIFORM;  // ... and those for large hierarchies the scalar node path
   static constexpr bool TRI_PREFETCH = TRIPF;  // ... and those for large meshes fetch a run's next triangle early
   static constexpr int THREADS = BLOCK;
-  static constexpr int ENTRIES = STACK;
   uint32_t* base;
-  uint32_t* csg;  // this lane's column of the CSG hit list (dynamic LDS), or null when the scene has no CSG
+  uint32_t* csg;  // this lane's column of the CSG hit list (behind the stack), or null when the scene has no CSG
   int sp;
-  DEV void init(uint32_t* lds, uint32_t* csg_lds = nullptr) {
+  int entries;    // per lane: what the scene's hierarchy can need (SceneDev::stack_entries), sized at launch
+  // lds: the workgroup's dynamic LDS, `entries` x BLOCK words of stack, then the CSG hit list
+  DEV void init(uint32_t* lds, int n_entries) {
     const uint32_t tid = (uint32_t)__lane_id();  // one wave per workgroup
     base = lds + tid;
-    csg = csg_lds ? csg_lds + tid : nullptr;
+    csg = CSG ? lds + (size_t)n_entries * BLOCK + tid : nullptr;
     sp = 0;
+    entries = n_entries;
   }
   DEV void push(uint32_t r) {
-    if (sp < STACK) base[(sp++) * BLOCK] = r;
+    if (sp < entries) base[(sp++) * BLOCK] = r;
   }
-  // Unconditional store, conditional advance: the slot above the top is scratch.  The host sizes
-  // the stack three entries above the deepest need, so the store never leaves the lane's column.
   DEV void push_if(uint32_t r, bool take) {
     base[sp * BLOCK] = r;
     sp += take ? 1 : 0;
@@ -377,7 +378,7 @@ DEV void traverse(const SceneDev& S, const Ray& ray, Query& Q, Stack& st, Counte
       for (uint32_t k = begin; __any(k < stop); k += 4) {
         const StripWords w = next;
         next = words_at(k + 4);  // in flight while these four are looked at
-        if (__any(st.sp + 4 > Stack::ENTRIES)) flush();
+        if (__any(st.sp + 4 > st.entries)) flush();
         st.push_if(k, k < stop && band_strip_passes(w.x, ls, lt, ls1024, lt1024));  // room for four was made above
         st.push_if(k + 1, k + 1 < stop && band_strip_passes(w.y, ls, lt, ls1024, lt1024));
         st.push_if(k + 2, k + 2 < stop && band_strip_passes(w.z, ls, lt, ls1024, lt1024));

@@ -211,6 +211,8 @@ struct SceneDev {
   int32_t n_inline_planes;
   int32_t band_items16;  // 1: band_items holds uint16_t entries (scenes of fewer than 65536 bounded cones)
   int32_t csg_hits;      // entries of the per-ray CSG hit list (CSG_MIN_HITS .. CSG_MAX_HITS)
+  int32_t stack_entries; // entries of the per-lane traversal stack the kernels are launched with (<= TRAVERSAL_STACK)
+  int32_t stack_pad;
 #ifdef RT_DIAG_NO_BANDS
   int32_t band_diag_passes;  // timing builds only: how many passes of the cone direction index run (0..3)
   int32_t band_diag_pad;

@@ -1,12 +1,15 @@
 """The acceleration structure built on the GPU (bvh_device.hip: Morton order, binary radix tree, collapse
-to the 4-wide layout) against the one the host builds (binned SAH): both are conservative hierarchies over
-the same shapes, so every image, hit leaf and ray count must be the same, bit for bit."""
+to the 4-wide layout) against the CPU oracle (the reference's algorithm: every child of every group scanned,
+src/shape.rs:1213-1219) and against the hierarchy the host builds (binned SAH): all are conservative over the
+same shapes, so every image, hit leaf and ray count must be the same."""
 import json
 import os
 import sys
 
 import numpy as np
 import pytest
+
+import oracle as orc
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,6 +47,21 @@ def both(pkg, text, size=None):
     return out
 
 
+def equals_oracle(render, text, size=None):
+    """The parity bar of tests/test_gpu_parity.py against the oracle's render of the same scene text."""
+    out, st = render
+    ref = orc.OracleScene(text, ROOT)
+    if size:
+        ref.set_canvas(*size)
+    want = ref.render(jobs=8)
+    assert np.array_equal(out["hit_leaf"], want["hit_leaf"])
+    assert np.array_equal(np.isnan(out["rgb64"]), np.isnan(want["rgb64"]))
+    assert np.nanmax(np.abs(out["rgb64"] - want["rgb64"]), initial=0.0) <= 1e-9
+    assert np.array_equal(out["rgb8"], orc.quantise(want["rgb64"]))
+    assert [st.primary, st.shadow, st.reflect, st.refract] == want["counts"]
+    return ref
+
+
 def same(a, b):
     (ra, sa), (rb, sb) = a, b
     assert np.array_equal(ra["hit_leaf"], rb["hit_leaf"])
@@ -63,6 +81,7 @@ def test_images_do_not_depend_on_the_builder(pkg, name, tmp_path):
         text = open(os.path.join(ROOT, "scenes", name + ".json")).read()
         size = (128, 72)
     (host, r_host, f_host), (dev, r_dev, f_dev) = both(pkg, text, size)
+    ref = equals_oracle(r_dev, text, size)  # the device-built hierarchy against the reference's algorithm
     same(r_host, r_dev)
     assert f_host["device_builds"] == 0
     if host.info()["leaves"] >= 4:  # a subtree of two items or more exists
@@ -74,6 +93,13 @@ def test_images_do_not_depend_on_the_builder(pkg, name, tmp_path):
     cb, lb, _ = dev.color_at(rays)
     assert np.array_equal(la, lb) and np.array_equal(ca, cb, equal_nan=True)
     assert np.array_equal(host.is_shadowed(rays[:, :3]), dev.is_shadowed(rays[:, :3]))
+    want, wleaf, counts = ref.color_at(rays)
+    assert np.array_equal(lb, wleaf) and np.array_equal(np.isnan(cb), np.isnan(want))
+    assert np.nanmax(np.abs(cb - want), initial=0.0) <= 1e-9
+    t, leaf = dev.intersect_hit(rays)
+    wt, wl = ref.intersect_hit(rays)
+    assert np.array_equal(leaf, wl) and np.array_equal(t[leaf >= 0], wt[leaf >= 0])
+    assert np.array_equal(dev.is_shadowed(rays[:, :3]), ref.is_shadowed(rays[:, :3]))
 
 
 def test_crowd_with_groups_built_on_the_device(pkg, tmp_path):
@@ -88,6 +114,7 @@ def test_crowd_with_groups_built_on_the_device(pkg, tmp_path):
         groups.append({"ty": "group", "children": shapes[k:k + 10] + [inner]})
     scene["shapes"] = groups + shapes[200:]
     (host, r_host, _), (dev, r_dev, f_dev) = both(pkg, json.dumps(scene))
+    equals_oracle(r_dev, json.dumps(scene))
     same(r_host, r_dev)
     assert f_dev["device_builds"] >= 9
 
@@ -128,7 +155,9 @@ def test_a_device_built_scene_is_updated_in_place(pkg):
     moving.update()
     with builder(False):
         fresh = pkg.Scene(json.dumps(scene), ROOT, device=0)
-    same(moving.render(), fresh.render())
+    moved = moving.render()
+    equals_oracle(moved, json.dumps(scene))
+    same(moved, fresh.render())
 
 
 class kernels:
@@ -154,7 +183,7 @@ def test_images_do_not_depend_on_the_kernel_variant(pkg, name, tmp_path):
         text = open(make_golden.synthetic_scene(name, str(tmp_path))).read()
     else:
         text = open(os.path.join(ROOT, "scenes", name + ".json")).read()
-        size = (320, 180)
+        size = (160, 90)
     out = []
     for large in (False, True):
         with kernels(large):
@@ -162,4 +191,5 @@ def test_images_do_not_depend_on_the_kernel_variant(pkg, name, tmp_path):
         if size:
             s.set_canvas(*size)
         out.append(s.render())
+    equals_oracle(out[1], text, size)
     same(out[0], out[1])
