@@ -44,11 +44,13 @@ RECORD_BYTES = 13 * 8 + 4 * 4  # one ray record of a generation buffer
 
 DEPTH = int(os.environ.get("RT_BENCH_DEPTH", "4"))  # frames in flight per GPU = host frames in the ring
 # Untimed frames before the warmup, as a stretch of their own that ends with every GPU idle.  A fresh process pays
-# about 11 ms once for its first launches (code objects, runtime pools), and a second part of that comes only after
-# some fifty to seventy frames of continuous work: with 64 priming frames it fell into the 20 timed frames of one
-# run in six (0.42 instead of 0.136 ms per frame; tools/probes/stall_probe.py).  Past the first hundred frames no
-# stretch of a process is slow again (600 stretches of 20 frames: 2.72 .. 2.99 ms).
-PRIMING = 256
+# about 20 ms once: code objects and runtime pools with the first launches, and about 5.6 ms for each of three DMA
+# engines on that engine's first copy -- the runtime turns to a second and third engine only when a copy finds the
+# others busy, which used to happen somewhere in the first hundred frames (one run in six had it inside its 20 timed
+# frames: 0.42 instead of 0.136 ms per frame).  The library now starts the engines before a device's first download
+# (prime_copy_engines in csrc/rt_api.cpp; tools/probes/stall_probe.py: no slow stretch after the first in 8 fresh
+# processes), so a short stretch is enough: clocks, caches, the first launches.
+PRIMING = 32
 
 
 def host_cores():
@@ -97,18 +99,25 @@ def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
     avg_ms = piped["kernel_ms"] / max(1, piped["kernel_launches"])
     lone_ms = lone["kernel_ms"] / max(1, lone["kernel_launches"])
     per_launch = flops_survey / launches
-    pmc, traffic = None, None
-    for name, key in (("pmc_f64.json", "f64_ops_per_launch"), ("traffic.json", "hbm_bytes_per_launch")):
+    # Counter figures collected by separate rocprofv3 --pmc runs of this bench (tools/gpu_round.sh) and kept under
+    # profiles/: quoted only while the kernel sources they were collected on are the ones in this tree.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_stamp import kernel_sources_sha256
+    tree = kernel_sources_sha256(ROOT)
+    counters, stale = {}, []
+    for name, keys in (("pmc_f64.json", ("f64_ops_per_launch", "valu_issue_busy", "td_busy", "active_lane_share")),
+                       ("traffic.json", ("hbm_bytes_per_launch",))):
         path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            try:
-                v = json.load(open(path)).get("k_generation", {}).get(key)
-            except Exception:
-                v = None
-            if name.startswith("pmc"):
-                pmc = v
-            else:
-                traffic = v
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
+        if doc.get("kernel_sources_sha256") != tree:
+            stale.append(name)
+            continue
+        for k in keys:
+            counters[k] = doc.get("k_generation", {}).get(k)
+    pmc, traffic = counters.get("f64_ops_per_launch"), counters.get("hbm_bytes_per_launch")
     frac = per_launch / (avg_ms * 1e-3) / FP64_VALU_PEAK
     return {
         "bound": "fp64_valu", "achieved": per_launch / (avg_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK / 1e12,
@@ -123,6 +132,11 @@ def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
         "f32_box_test_ops_per_launch": f32_ops / launches,
         "pmc_f64_ops_per_launch": pmc,
         "frac_pmc_f64": None if not pmc else pmc / (avg_ms * 1e-3) / FP64_VALU_PEAK,
+        # the ceilings that bind this kernel, from the same counter runs (lone launches under the profiler)
+        "valu_issue_busy": counters.get("valu_issue_busy"), "td_busy": counters.get("td_busy"),
+        "active_lane_share": counters.get("active_lane_share"),
+        "counters_note": ("profiles/%s were collected on other kernel sources than this tree's: not quoted" % " and ".join(stale)) if stale
+                         else "traffic and counter figures: profiles/traffic.json, profiles/pmc_f64.json, collected on this tree's kernel sources",
         "hbm_bytes_per_launch": hbm / launches, "frac_hbm": hbm / launches / (avg_ms * 1e-3) / HBM_PEAK,
         "plan_bytes_per_launch": plan_bytes / launches,
         "plan_bytes_over_hbm_peak": plan_bytes / launches / (avg_ms * 1e-3) / HBM_PEAK,

@@ -3,7 +3,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "rt_error.h"
@@ -251,12 +253,56 @@ static int order_copy_stream(rt_scene* s, void* after_stream) {
   return RT_OK;
 }
 
+// The first device-to-host copies of a process are slow in a way that does not show at once: the runtime sets up
+// every DMA engine it hands copies to on that engine's first use (measured here: about 5.6 ms each, three of them),
+// and it picks a second and a third engine only when a copy finds the first ones busy -- which in a frame loop
+// happens some time within the first hundred frames (tools/probes/stall_probe.py: the loop without copies shows no
+// such stall).  Before a device's first download the engines are therefore made to start: several copies on streams
+// of their own, in flight together.
+static int prime_copy_engines(int device) {
+  static std::mutex guard;
+  static bool done[64] = {};
+  std::lock_guard<std::mutex> lock(guard);
+  if (device < 0 || device >= 64 || done[device]) return RT_OK;
+  done[device] = true;
+  static const bool off = getenv("RT_AMD_NO_COPY_PRIMING") != nullptr;
+  if (off) return RT_OK;
+  constexpr int COPIES = 8, ROUNDS = 3;
+  constexpr size_t BYTES = 4u << 20;
+  void* dev = nullptr;
+  char* host = nullptr;
+  hipStream_t streams[COPIES] = {};
+  int rc = RT_OK;
+  auto check = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == RT_OK) {
+      (void)hipGetLastError();
+      rc = fail(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    }
+  };
+  check(hipMalloc(&dev, BYTES), "hipMalloc");
+  check(hipHostMalloc((void**)&host, COPIES * BYTES, hipHostMallocDefault), "hipHostMalloc");
+  for (hipStream_t& st : streams)
+    if (rc == RT_OK) check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+  for (int r = 0; r < ROUNDS && rc == RT_OK; r++) {
+    for (int k = 0; k < COPIES && rc == RT_OK; k++)
+      check(hipMemcpyAsync(host + (size_t)k * BYTES, dev, BYTES, hipMemcpyDeviceToHost, streams[k]), "hipMemcpyAsync");
+    for (int k = 0; k < COPIES && rc == RT_OK; k++) check(hipStreamSynchronize(streams[k]), "hipStreamSynchronize");
+  }
+  for (hipStream_t st : streams)
+    if (st) (void)hipStreamDestroy(st);
+  if (host) (void)hipHostFree(host);
+  if (dev) (void)hipFree(dev);
+  return rc;
+}
+
 extern "C" int rt_download_2d(rt_scene* s, const void* src_dev, void* dst_host, uint64_t row_bytes, uint64_t rows,
                               uint64_t pitch, void* after_stream) {
   if (!s || (row_bytes && rows && (!src_dev || !dst_host))) return fail(RT_ERR_INVALID, "null argument");
   if (pitch < row_bytes) return fail(RT_ERR_INVALID, "pitch smaller than a row");
   HIP_TRY(hipSetDevice(s->device));
   if (row_bytes == 0 || rows == 0) return RT_OK;
+  int rcp = prime_copy_engines(s->device);
+  if (rcp) return rcp;
   int rco = order_copy_stream(s, after_stream);
   if (rco) return rco;
   HIP_TRY(hipMemcpy2DAsync(dst_host, pitch, src_dev, pitch, row_bytes, rows, hipMemcpyDeviceToHost, s->copy_stream));
@@ -267,6 +313,8 @@ extern "C" int rt_download(rt_scene* s, const void* src_dev, void* dst_host, uin
   if (!s || (bytes && (!src_dev || !dst_host))) return fail(RT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(s->device));
   if (bytes == 0) return RT_OK;
+  int rcp = prime_copy_engines(s->device);
+  if (rcp) return rcp;
   int rco = order_copy_stream(s, after_stream);
   if (rco) return rco;
   // a plain asynchronous copy: the runtime moves it with a DMA engine, which leaves the compute units

@@ -12,6 +12,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_stamp import kernel_sources_sha256  # noqa: E402
+
 root, out = sys.argv[1], sys.argv[2]
 tot, disp = defaultdict(float), defaultdict(set)
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -34,6 +37,11 @@ res = {"k_generation": {
     "active_lane_share": lanes,
     "f64_ops_per_launch_active_lanes": None if lanes is None else 64.0 * (add + mul + 2.0 * fma) * lanes,
     "formula": "64 lanes x (ADD_F64 + MUL_F64 + 2 FMA_F64) wave-level instructions, mean per launch",
-}}
+    # what binds the kernel when it is not arithmetic: the share of issue slots taken (a wave instruction occupies a
+    # SIMD for 4 clocks; 1024 SIMDs) and the share of time the vector-memory return path is busy (256 TDs), over
+    # the clocks the launches were resident (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+    "valu_issue_busy": None if not per.get("GRBM_GUI_ACTIVE") else valu * 4.0 / (1024.0 * per["GRBM_GUI_ACTIVE"] / 8.0),
+    "td_busy": None if not (per.get("GRBM_GUI_ACTIVE") and per.get("TD_TD_BUSY_sum")) else per["TD_TD_BUSY_sum"] / (256.0 * per["GRBM_GUI_ACTIVE"] / 8.0),
+}, "kernel_sources_sha256": kernel_sources_sha256()}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res["k_generation"], indent=1))

@@ -15,6 +15,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_stamp import kernel_sources_sha256  # noqa: E402
+
 root, out = sys.argv[1], sys.argv[2]
 tot = defaultdict(float)
 disp = defaultdict(set)
@@ -31,6 +34,6 @@ res = {"k_generation": {
     "launches_seen": [len(disp["FETCH_SIZE"]), len(disp["WRITE_SIZE"])],
     "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
     "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes; gfx950 FETCH_SIZE halving corrected",
-}}
+}, "kernel_sources_sha256": kernel_sources_sha256()}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
