@@ -444,7 +444,7 @@ def bench_ranks(args, world):
     host_s, host_stats = timed_loop(True)
     last = (args.steps - 1) % DEPTH
     if not assembled_by_dma:  # outside the timed region: the ranks' bands of the last frame put together for the checksum
-        for y0, y1 in pkg.tiles.part_bands(H, rank, world):
+        for y0, y1 in pkg.tiles.part_bands(H, rank, world, loop.band_rows):
             shared.frame(last)[y0:y1] = ring.frame(last)[y0:y1]
         sync()
     sha = hashlib.sha256(shared.frame(last).tobytes()).hexdigest() if rank == 0 else None

@@ -201,7 +201,9 @@ enum {
   RT_FLAG_COUNTERS = 1, /* run the instrumented kernels and fill the work counters */
   RT_FLAG_ASYNC = 2,    /* rt_render only: enqueue the frame and return; see rt_scene_wait */
   RT_FLAG_COMPACT = 4,  /* rt_render only: rgb8_dev receives just this part's pixels, see rt_render */
-  RT_FLAG_BANDS = 8     /* rt_render only: parts are bands of 32 pixel rows, band b belongs to part b % n_parts */
+  RT_FLAG_BANDS = 8,    /* rt_render only: parts are bands of 32 pixel rows, band b belongs to part b % n_parts */
+  RT_FLAG_BANDS_16 = 16, /* with RT_FLAG_BANDS: bands of 16 rows (finer bands spread the expensive rows over the parts */
+  RT_FLAG_BANDS_8 = 32   /* more evenly) ... of 8 rows */
 };
 
 const char* rt_last_error(void);

@@ -18,6 +18,8 @@ RT_FLAG_COUNTERS = 1
 RT_FLAG_ASYNC = 2
 RT_FLAG_COMPACT = 4
 RT_FLAG_BANDS = 8
+RT_FLAG_BANDS_16 = 16
+RT_FLAG_BANDS_8 = 32
 
 
 class RtError(RuntimeError):
@@ -417,6 +419,13 @@ class FrameLoop:
         buf = (C.c_uint8 * (self.width * self.height * 3)).from_address(p)
         return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 3)
 
+    @property
+    def band_rows(self):
+        """Rows of a band of this loop's parts (32, or what RT_AMD_BAND_ROWS asked for when the loop was made)."""
+        self._host.rth_frame_loop_band_rows.restype = C.c_uint64
+        self._host.rth_frame_loop_band_rows.argtypes = [C.c_void_p]
+        return int(self._host.rth_frame_loop_band_rows(self._l))
+
     def info(self):
         out = (C.c_uint64 * 2)()
         b = C.c_double()
@@ -546,13 +555,13 @@ class Scene:
         return out, st
 
     def render_device(self, rgb8_ptr=0, rgb64_ptr=0, hit_leaf_ptr=0, part=0, n_parts=1, counters=False, wait=True,
-                      compact=False, bands=False):
+                      compact=False, bands=False, band_rows=32):
         """rt_render into device buffers given by address (e.g. torch tensor .data_ptr()).  With
         wait=False the frame is only enqueued (RT_FLAG_ASYNC); collect with wait()."""
         cam = self.camera()
         st = RtStats()
         flags = ((RT_FLAG_COUNTERS if counters else 0) | (0 if wait else RT_FLAG_ASYNC) | (RT_FLAG_COMPACT if compact else 0)
-                 | (RT_FLAG_BANDS if bands else 0))
+                 | (RT_FLAG_BANDS if bands else 0) | ({32: 0, 16: RT_FLAG_BANDS_16, 8: RT_FLAG_BANDS_8}[band_rows] if bands else 0))
         self._check(self._amd.rt_render(self._dev(), C.byref(cam), part, n_parts, flags,
                                         C.c_void_p(rgb8_ptr or None), C.c_void_p(rgb64_ptr or None),
                                         C.c_void_p(hit_leaf_ptr or None), C.byref(st)))

@@ -135,6 +135,9 @@ extern "C" int rt_scene_footprint(const rt_scene* s, uint64_t* scene_bytes, doub
   return RT_OK;
 }
 
+// rows of a band under RT_FLAG_BANDS: 32, or 16 / 8 when the caller asks for finer bands
+static uint32_t band_rows(uint32_t flags) { return (flags & RT_FLAG_BANDS_8) ? 8u : ((flags & RT_FLAG_BANDS_16) ? 16u : 32u); }
+
 extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_parts, uint32_t flags,
                          uint8_t* rgb8_dev, double* rgb64_dev, int32_t* hit_leaf_dev, rt_stats* stats) {
   if (!s || !camera) return fail(RT_ERR_INVALID, "null argument");
@@ -145,9 +148,10 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   RT_REQUIRE_USABLE(s);
   HIP_TRY(hipSetDevice(s->device));
   if (stats) memset(stats, 0, sizeof(*stats));
-  uint32_t tiles_x = (camera->hsize + TILE - 1) / TILE, tiles_y = (camera->vsize + TILE - 1) / TILE;
   const bool bands = (flags & RT_FLAG_BANDS) != 0;
-  const uint32_t key[4] = {camera->hsize, camera->vsize, (uint32_t)part | (bands ? 0x80000000u : 0u), (uint32_t)n_parts};
+  const uint32_t tile_h = bands ? band_rows(flags) : (uint32_t)TILE;
+  uint32_t tiles_x = (camera->hsize + TILE - 1) / TILE, tiles_y = (camera->vsize + tile_h - 1) / tile_h;
+  const uint32_t key[4] = {camera->hsize, camera->vsize, (uint32_t)part | (bands ? 0x80000000u : 0u) | (tile_h << 20), (uint32_t)n_parts};
   if (memcmp(key, s->tiles_key, sizeof(key)) != 0) {
     int rcw = collect_all(s);  // frames in flight still read the current tile table
     if (rcw) return rcw;
@@ -169,7 +173,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
       HIP_TRY(hipMemcpy(s->d_tiles, s->h_tiles.data(), s->h_tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     memcpy(s->tiles_key, key, sizeof(key));
   }
-  uint64_t n64 = (uint64_t)s->h_tiles.size() * TILE_PIXELS;
+  uint64_t n64 = (uint64_t)s->h_tiles.size() * TILE * tile_h;
   if (n64 > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "canvas part exceeds 2^32 rays");
   if (n64 == 0) return RT_OK;
   PipelineIn in;
@@ -177,6 +181,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   in.flags = flags;
   in.camera = true;
   in.cam = camera_dev(camera);
+  in.cam.tile_h = tile_h;
+  in.cam.tile_shift = tile_h == 8 ? 8u : (tile_h == 16 ? 9u : 10u);
   in.tiles = n_parts == 1 ? nullptr : s->d_tiles;  // the whole image: tile k is tile k, no look-up at the start of every wave
   in.tiles_x = tiles_x;
   if ((flags & RT_FLAG_COMPACT) && (rgb64_dev || hit_leaf_dev || !rgb8_dev))
@@ -184,8 +190,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   in.img = ImageOut{rgb8_dev, rgb64_dev, hit_leaf_dev, (flags & RT_FLAG_COMPACT) ? 1u : 0u};
   uint64_t valid = 0;
   for (uint32_t t : s->h_tiles) {
-    uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * TILE;
-    uint32_t w = std::min<uint32_t>(TILE, camera->hsize - x0), h = std::min<uint32_t>(TILE, camera->vsize - y0);
+    uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * tile_h;
+    uint32_t w = std::min<uint32_t>(TILE, camera->hsize - x0), h = std::min<uint32_t>(tile_h, camera->vsize - y0);
     valid += (uint64_t)w * h;
   }
   if ((flags & RT_FLAG_ASYNC) && s->max_children == 0) return enqueue_direct_frame(s, in, valid);
@@ -355,10 +361,10 @@ extern "C" int rt_render_host(rt_scene* s, const rt_camera* camera, int part, in
                  rgb64 ? (double*)(base + off64) : nullptr, hit_leaf ? (int32_t*)(base + offl) : nullptr, stats);
   if (rc) return rc;
   if ((flags & RT_FLAG_BANDS) && n_parts > 1) {
-    // only this part's bands of 32 rows go to the host images, so the parts of one frame can share them
-    const size_t rows_total = camera->vsize, w = camera->hsize;
-    for (size_t y0 = (size_t)part * TILE; y0 < rows_total; y0 += (size_t)n_parts * TILE) {
-      const size_t rows = std::min<size_t>(TILE, rows_total - y0), px = y0 * w, n = rows * w;
+    // only this part's bands go to the host images, so the parts of one frame can share them
+    const size_t rows_total = camera->vsize, w = camera->hsize, band = band_rows(flags);
+    for (size_t y0 = (size_t)part * band; y0 < rows_total; y0 += (size_t)n_parts * band) {
+      const size_t rows = std::min<size_t>(band, rows_total - y0), px = y0 * w, n = rows * w;
       if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8 + px * 3, base + px * 3, n * 3, hipMemcpyDeviceToHost, main_stream(s)));
       if (rgb64)
         HIP_TRY(hipMemcpyAsync(rgb64 + px * 3, base + off64 + px * 3 * sizeof(double), n * 3 * sizeof(double),

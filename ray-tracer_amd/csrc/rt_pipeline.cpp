@@ -95,6 +95,8 @@ CameraDev rt::camera_dev(const rt_camera* c) {
   cd.half_height = c->half_height;
   cd.pixel_size = c->pixel_size;
   copy3x4(cd.inv, c->inv);
+  cd.tile_h = TILE;
+  cd.tile_shift = 10;
   // Matrix4D * point(0, 0, 0) as the device would form it (src/matrix.rs:638-653): products with zero stay in
   for (int r = 0; r < 3; r++) {
     const double* m = cd.inv + 4 * r;

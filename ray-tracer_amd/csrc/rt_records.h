@@ -24,6 +24,8 @@ struct CameraDev {
   double half_width, half_height, pixel_size;
   double inv[12];
   double origin[3];  // inv * point(0, 0, 0), the same for every pixel (src/camera.rs:91)
+  // A part of a frame is made of tiles 32 pixels wide and tile_h = 8, 16 or 32 high (2^tile_shift pixels each)
+  uint32_t tile_h, tile_shift;
 };
 
 struct ImageOut {
@@ -62,8 +64,7 @@ struct GenLaunch {
   ShadowView aside{};
 };
 
-constexpr int TILE = 32;  // multi-GPU partition granule, pixels per side
-constexpr int TILE_PIXELS = TILE * TILE;
+constexpr int TILE = 32;  // multi-GPU partition granule: pixels per side of a tile, rows of a band unless the caller asks for 16 or 8
 constexpr int BLOCK = 64;  // threads per workgroup of every kernel: one wave
 // Thread index within the workgroup: the lane id, which costs two instructions to recompute wherever
 // it is needed instead of occupying a register for the whole kernel.
@@ -97,11 +98,11 @@ constexpr int STAT_WORDS = STAT_RAYS + 3 * STAT_SLOTS + STAMP_WORDS;
 // 64 rays of a wave stay close in screen space.
 DEV bool ray_pixel(const uint32_t* tiles, uint32_t tiles_x, const CameraDev& cam, uint32_t i, uint32_t& x,
                    uint32_t& y) {
-  uint32_t tile = tiles ? tiles[i / TILE_PIXELS] : i / TILE_PIXELS;  // no table: the part owns every tile, in order
-  uint32_t in_tile = i % TILE_PIXELS;
+  uint32_t tile = tiles ? tiles[i >> cam.tile_shift] : i >> cam.tile_shift;  // no table: the part owns every tile, in order
+  uint32_t in_tile = i & ((1u << cam.tile_shift) - 1u);
   uint32_t wave = in_tile >> 6, lane = in_tile & 63u;
   x = (tile % tiles_x) * TILE + (wave & 3u) * 8u + (lane & 7u);
-  y = (tile / tiles_x) * TILE + (wave >> 2) * 8u + (lane >> 3);
+  y = (tile / tiles_x) * cam.tile_h + (wave >> 2) * 8u + (lane >> 3);
   return x < cam.hsize && y < cam.vsize;
 }
 

@@ -1183,6 +1183,11 @@ FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector
   total_parts_ = share.total_parts ? share.total_parts : devices.size();
   if (first_part_ + devices.size() > total_parts_) throw std::invalid_argument("FrameLoop: more parts than the frame has");
   own_ring_ = share.ring == nullptr;
+  if (const char* e = getenv("RT_AMD_BAND_ROWS")) {
+    const int rows = atoi(e);
+    if (rows != 8 && rows != 16 && rows != 32) throw std::invalid_argument("RT_AMD_BAND_ROWS must be 8, 16 or 32");
+    band_rows_ = (size_t)rows;
+  }
   cam_ = camera.describe();
   frame_bytes_ = (size_t)cam_.hsize * cam_.vsize * 3;
   if (frame_bytes_ == 0) throw std::invalid_argument("FrameLoop: empty canvas");
@@ -1230,6 +1235,10 @@ uint64_t FrameLoop::scene_bytes() const {
   return b;
 }
 
+uint32_t FrameLoop::band_flags() const {
+  return RT_FLAG_BANDS | (band_rows_ == 8 ? RT_FLAG_BANDS_8 : (band_rows_ == 16 ? RT_FLAG_BANDS_16 : 0u));
+}
+
 FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
   const size_t workers = scenes_.size(), n = total_parts_;  // n: parts of the frame, of which this loop renders `workers`
   Result result;
@@ -1237,7 +1246,8 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
   std::vector<std::string> errors(workers);
   Rendezvous meet(workers);
   std::chrono::steady_clock::time_point t0, t1;
-  const size_t w = cam_.hsize, rows_total = cam_.vsize, band_bytes = (size_t)32 * w * 3;
+  const size_t w = cam_.hsize, rows_total = cam_.vsize, band = band_rows_, band_bytes = band * w * 3;
+  const uint32_t part_flags = band_flags();
   // A fence on the copy stream after every copy costs about 5 us of the copy engine's time (the next
   // copy starts only when the fence's marker has gone through the stream's queue).  Copies on one stream
   // finish in order, so a fence after every `stride`-th copy tells as much: a slot is free once a fence
@@ -1259,7 +1269,7 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
       uint8_t* dev = dev_frames_[k][(size_t)slot];
       // the copy that last read this device frame (depth frames ago) must be through before it is rendered over
       if (to_host && fenced_by[(size_t)slot] >= 0 && rt_copy_wait(sc, (uint32_t)fenced_by[(size_t)slot]) != RT_OK) ok = false;
-      if (ok && rt_render(sc, &cam_, (int)part, (int)n, RT_FLAG_ASYNC | RT_FLAG_BANDS, dev, nullptr, nullptr, nullptr) != RT_OK) ok = false;
+      if (ok && rt_render(sc, &cam_, (int)part, (int)n, RT_FLAG_ASYNC | part_flags, dev, nullptr, nullptr, nullptr) != RT_OK) ok = false;
       auto fence = [&]() {  // after this slot's copy has been enqueued
         unfenced.push_back(slot);
         if (unfenced.size() < stride && f != last_frame) return;
@@ -1272,14 +1282,14 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
         if (ok) fence();
       } else if (ok && to_host) {
         // this part's bands: whole bands with one strided copy, a last partial band with a plain one
-        const size_t first = part * 32, n_bands_mine = first < rows_total ? (rows_total - first + n * 32 - 1) / (n * 32) : 0;
+        const size_t first = part * band, n_bands_mine = first < rows_total ? (rows_total - first + n * band - 1) / (n * band) : 0;
         size_t whole = n_bands_mine;
-        if (n_bands_mine && first + (n_bands_mine - 1) * n * 32 + 32 > rows_total) whole--;
+        if (n_bands_mine && first + (n_bands_mine - 1) * n * band + band > rows_total) whole--;
         uint8_t* host = host_[(size_t)slot];
         const size_t off = first * w * 3;
         if (whole && rt_download_2d(sc, dev + off, host + off, band_bytes, whole, n * band_bytes, nullptr) != RT_OK) ok = false;
         if (ok && whole != n_bands_mine) {
-          const size_t y0 = first + whole * n * 32, o = y0 * w * 3;
+          const size_t y0 = first + whole * n * band, o = y0 * w * 3;
           if (rt_download(sc, dev + o, host + o, (rows_total - y0) * w * 3, nullptr) != RT_OK) ok = false;
         }
         if (ok) fence();
@@ -1319,7 +1329,7 @@ std::vector<rt_stats> FrameLoop::blocking_frames(size_t frames, bool counters) {
   for (size_t f = 0; f < frames; f++)
     for (size_t k = 0; k < scenes_.size(); k++) {
       rt_stats st{};
-      check_rt(rt_render(scenes_[k], &cam_, (int)(first_part_ + k), (int)total_parts_, (counters ? RT_FLAG_COUNTERS : 0u) | RT_FLAG_BANDS,
+      check_rt(rt_render(scenes_[k], &cam_, (int)(first_part_ + k), (int)total_parts_, (counters ? RT_FLAG_COUNTERS : 0u) | band_flags(),
                          dev_frames_[k][0], nullptr, nullptr, &st));
       rt_stats& o = out[k];
       o.primary += st.primary; o.shadow += st.shadow; o.reflect += st.reflect; o.refract += st.refract;

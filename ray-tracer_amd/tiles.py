@@ -45,11 +45,11 @@ def compact_pixel_index(width, height, part, n_parts, device="cpu", outside=-1):
     return idx.reshape(-1).to(device)
 
 
-def part_bands(height, part, n_parts):
-    """Row ranges [(y0, y1), ...] of the bands of 32 pixel rows that belong to `part` under
+def part_bands(height, part, n_parts, rows=TILE):
+    """Row ranges [(y0, y1), ...] of the bands of `rows` pixel rows (32, 16 or 8) that belong to `part` under
     RT_FLAG_BANDS (band b belongs to part b % n_parts)."""
-    n_bands = (height + TILE - 1) // TILE
-    return [(b * TILE, min(height, (b + 1) * TILE)) for b in range(part, n_bands, n_parts)]
+    n_bands = (height + rows - 1) // rows
+    return [(b * rows, min(height, (b + 1) * rows)) for b in range(part, n_bands, n_parts)]
 
 
 def download_bands(scene, frame_ptr, host_ptr, width, height, part, n_parts, after_stream=0):

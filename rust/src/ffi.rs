@@ -37,6 +37,8 @@ pub const RT_FLAG_COUNTERS: u32 = 1;
 pub const RT_FLAG_ASYNC: u32 = 2;
 pub const RT_FLAG_COMPACT: u32 = 4;
 pub const RT_FLAG_BANDS: u32 = 8;
+pub const RT_FLAG_BANDS_16: u32 = 16;
+pub const RT_FLAG_BANDS_8: u32 = 32;
 // build_flags of rt_scene_create_with
 pub const RT_BUILD_DEVICE: u32 = 1;
 

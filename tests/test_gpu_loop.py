@@ -59,6 +59,43 @@ def test_loops_that_render_some_parts_share_a_ring(pkg, root):
     ring.close()
 
 
+@pytest.mark.parametrize("rows", [16, 8])
+def test_finer_bands_assemble_the_same_frame(pkg, root, rows):
+    """Bands of 16 and 8 rows instead of 32 (RT_FLAG_BANDS_16 / _8; RT_AMD_BAND_ROWS for the frame loop): the parts of
+    a frame rendered with finer bands put together the frame one part renders, on a canvas whose height is no
+    multiple of the band height."""
+    import torch
+    scene = pkg.Scene.from_file(os.path.join(root, "scenes", "glass.json"), base_dir=root, device=0)
+    w, h = 200, 141
+    scene.set_canvas(w, h)
+    want, _ = scene.render()
+    for n in (2, 3, 5):
+        frame = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+        for part in range(n):
+            scene.render_device(rgb8_ptr=frame.data_ptr(), part=part, n_parts=n, bands=True, band_rows=rows)
+            mine = torch.zeros(h, dtype=torch.bool)
+            for y0, y1 in pkg.tiles.part_bands(h, part, n, rows):
+                mine[y0:y1] = True
+            got = frame.cpu().numpy()
+            # rows of other parts rendered so far or still empty; this part's rows are final
+            assert np.array_equal(got[mine.numpy()], want["rgb8"][mine.numpy()])
+        assert np.array_equal(frame.cpu().numpy(), want["rgb8"])
+    os.environ["RT_AMD_BAND_ROWS"] = str(rows)
+    try:
+        host_scene = pkg.Scene.from_file(os.path.join(root, "scenes", "teapot.json"), base_dir=root, device=None)
+        host_scene.set_canvas(320, 180)
+        loop = host_scene.frame_loop([0, 0, 0], depth=2)
+        assert loop.band_rows == rows
+        loop.run(1, 3, True)
+        got = loop.host_frame(1).copy()  # frames 0..3 went to slots 0, 1, 0, 1
+        loop.close()
+    finally:
+        os.environ.pop("RT_AMD_BAND_ROWS", None)
+    one = pkg.Scene.from_file(os.path.join(root, "scenes", "teapot.json"), base_dir=root, device=0)
+    one.set_canvas(320, 180)
+    assert np.array_equal(got, one.render()[0]["rgb8"])
+
+
 def test_clone_renders_the_same_frame(pkg, root):
     import ctypes as C
     amd, _ = pkg.bindings.libraries()
