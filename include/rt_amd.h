@@ -31,7 +31,8 @@ typedef enum rt_status {
   RT_OK = 0,
   RT_ERR_INVALID = -1,     /* bad argument or inconsistent description */
   RT_ERR_UNSUPPORTED = -2, /* valid for the reference, not built here: projective transforms, a CSG operator tree whose
-                              shapes can yield more than 60 intersections per ray, operators nested more than 32 deep */
+                              shapes can yield more than 4096 intersections per ray, operators nested more than 32 deep,
+                              a recursion deeper than 4096 */
   RT_ERR_DEVICE = -3,      /* HIP runtime failure */
   RT_ERR_NOMEM = -4
 } rt_status;

@@ -1,6 +1,8 @@
 // The generation kernel: one ray per lane from camera or queue to its surface colour, and the
 // launcher of its instantiations.
 #pragma once
+#include <algorithm>
+
 #include "rt_launch.h"
 #include "rt_shading.h"
 #include "rt_traverse.h"
@@ -64,6 +66,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
       wave_index = ((k / XCD_RUN) * XCDS + xcd) * XCD_RUN + k % XCD_RUN;
     }
   }
+  wave_index += S.first_block;  // a job launched in pieces (SceneDev::csg_spill_slots)
   const uint32_t i = wave_index * BLOCK + thread_in_block();
   uint32_t rec = i;
   bool active = i < n;
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(BLOCK, RT_MIN_WAVES)
   extern __shared__ uint32_t dyn_lds[];
   LdsStack<BLOCK, CSG, UNIFORM, false> st;
   st.init(dyn_lds, S.stack_entries);
-  const uint32_t i = blockIdx.x * BLOCK + thread_in_block();
+  const uint32_t i = (blockIdx.x + S.first_block) * BLOCK + thread_in_block();
   uint32_t slot = 0;
   const bool active = queue_slot(q.counts, q.segcap, i, slot) && i < n;  // n only bounds the grid
   if (!__any(active)) return;
@@ -383,23 +386,39 @@ __global__ void __launch_bounds__(BLOCK, RT_MIN_WAVES)
 // of the shadow queries it set aside (a.aside.segcap != 0: scenes with bounded cones).  Defined where the
 // kernels are instantiated (rt_gen_*.hip); rt_launch.h declares it for the host pipeline.
 template <bool COUNT, bool CSG, bool UNIFORM, bool TRIPF>
-void launch_generation_variant(const SceneDev& dev, unsigned lds_bytes, int mode, const GenLaunch& a) {
-  dim3 grid((a.n + BLOCK - 1) / BLOCK), block(BLOCK);
-#define RT_GEN_ARGS dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap, a.aside
-  if constexpr (TRIPF) {  // only camera rays of scenes that spawn nothing fetch triangles ahead
-    hipLaunchKernelGGL((k_generation<COUNT, 0, CSG, UNIFORM, true>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS);
-  } else {
-    switch (mode) {
-      case 0: hipLaunchKernelGGL((k_generation<COUNT, 0, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS); break;
-      case 1: hipLaunchKernelGGL((k_generation<COUNT, 1, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS); break;
-      default: hipLaunchKernelGGL((k_generation<COUNT, 2, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS); break;
+void launch_generation_variant(const SceneDev& scene, unsigned lds_bytes, int mode, const GenLaunch& a) {
+  const dim3 block(BLOCK);
+  // a scene whose CSG hit lists live in device memory owns csg_spill_slots of them: its jobs go in pieces
+  auto in_pieces = [&](uint32_t blocks, auto&& launch) {
+    if (!scene.csg_spill) {
+      launch(scene, dim3(blocks));
+      return;
     }
-  }
+    for (uint32_t first = 0; first < blocks; first += scene.csg_spill_slots) {
+      SceneDev piece = scene;
+      piece.first_block = first;
+      launch(piece, dim3(std::min(scene.csg_spill_slots, blocks - first)));
+    }
+  };
+#define RT_GEN_ARGS dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap, a.aside
+  in_pieces((a.n + BLOCK - 1) / BLOCK, [&](const SceneDev& dev, dim3 grid) {
+    if constexpr (TRIPF) {  // only camera rays of scenes that spawn nothing fetch triangles ahead
+      hipLaunchKernelGGL((k_generation<COUNT, 0, CSG, UNIFORM, true>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS);
+    } else {
+      switch (mode) {
+        case 0: hipLaunchKernelGGL((k_generation<COUNT, 0, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS); break;
+        case 1: hipLaunchKernelGGL((k_generation<COUNT, 1, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS); break;
+        default: hipLaunchKernelGGL((k_generation<COUNT, 2, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS); break;
+      }
+    }
+  });
 #undef RT_GEN_ARGS
   if (a.aside.segcap != 0u) {  // the grid covers the queue's room; waves beyond its end exit at once
     const uint32_t room = a.aside.segcap * QUEUE_SEGMENTS;
-    hipLaunchKernelGGL((k_shadow<COUNT, CSG, UNIFORM>), dim3((room + BLOCK - 1) / BLOCK), block, lds_bytes, a.stream, dev,
-                       a.aside, room, a.cur, mode, a.stats, a.cam, a.tiles, a.tiles_x, a.img);
+    in_pieces((room + BLOCK - 1) / BLOCK, [&](const SceneDev& dev, dim3 grid) {
+      hipLaunchKernelGGL((k_shadow<COUNT, CSG, UNIFORM>), grid, block, lds_bytes, a.stream, dev, a.aside, room, a.cur, mode, a.stats,
+                         a.cam, a.tiles, a.tiles_x, a.img);
+    });
   }
 }
 

@@ -1,5 +1,7 @@
 // The small kernels around the generation kernel: loading caller rays, resolving colours back through
 // the generations, the per-ray entry points of the C ABI, and the refit of the hierarchy.
+#include <algorithm>
+
 #include "rt_launch.h"
 #include "rt_shading.h"
 #include "rt_traverse.h"
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(BLOCK)
 template <bool CSG>
 __global__ void __launch_bounds__(BLOCK) k_intersect(SceneDev S, GenView g, uint32_t n) {
   extern __shared__ uint32_t dyn_lds[];  // traversal stack, then the CSG hit list (see k_generation)
-  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  uint32_t i = (blockIdx.x + S.first_block) * BLOCK + threadIdx.x;
   if (i >= n) return;
   LdsStack<BLOCK, CSG> st;
   st.init(dyn_lds, S.stack_entries);
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect(SceneDev S, GenView g, uint
 template <bool CSG>
 __global__ void __launch_bounds__(BLOCK) k_points_shadowed(SceneDev S, uint32_t n, const double* pts, uint8_t* out) {
   extern __shared__ uint32_t dyn_lds[];  // traversal stack, then the CSG hit list (see k_generation)
-  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  uint32_t i = (blockIdx.x + S.first_block) * BLOCK + threadIdx.x;
   if (i >= n) return;
   LdsStack<BLOCK, CSG> st;
   st.init(dyn_lds, S.stack_entries);
@@ -232,14 +234,32 @@ void launch_resolve_pixels(hipStream_t stream, GenView g, uint32_t n, GenView ne
 void launch_output_rays(hipStream_t stream, GenView g, uint32_t n, double* rgb, int32_t* leaf, double* t) {
   hipLaunchKernelGGL(k_output_rays, grid_for(n), dim3(BLOCK), 0, stream, g, n, rgb, leaf, t);
 }
-void launch_intersect(hipStream_t stream, const SceneDev& dev, bool general, unsigned lds_bytes, GenView g, uint32_t n) {
-  if (general) hipLaunchKernelGGL((k_intersect<true>), grid_for(n), dim3(BLOCK), lds_bytes, stream, dev, g, n);
-  else hipLaunchKernelGGL((k_intersect<false>), grid_for(n), dim3(BLOCK), lds_bytes, stream, dev, g, n);
+// a scene whose CSG hit lists live in device memory owns csg_spill_slots of them: its jobs go in pieces
+template <class Launch>
+static void in_pieces(const SceneDev& scene, uint64_t n, Launch&& launch) {
+  const uint32_t blocks = grid_for(n).x;
+  if (!scene.csg_spill) {
+    launch(scene, dim3(blocks));
+    return;
+  }
+  for (uint32_t first = 0; first < blocks; first += scene.csg_spill_slots) {
+    SceneDev piece = scene;
+    piece.first_block = first;
+    launch(piece, dim3(std::min(scene.csg_spill_slots, blocks - first)));
+  }
 }
-void launch_points_shadowed(hipStream_t stream, const SceneDev& dev, bool general, unsigned lds_bytes, uint32_t n,
+void launch_intersect(hipStream_t stream, const SceneDev& scene, bool general, unsigned lds_bytes, GenView g, uint32_t n) {
+  in_pieces(scene, n, [&](const SceneDev& dev, dim3 grid) {
+    if (general) hipLaunchKernelGGL((k_intersect<true>), grid, dim3(BLOCK), lds_bytes, stream, dev, g, n);
+    else hipLaunchKernelGGL((k_intersect<false>), grid, dim3(BLOCK), lds_bytes, stream, dev, g, n);
+  });
+}
+void launch_points_shadowed(hipStream_t stream, const SceneDev& scene, bool general, unsigned lds_bytes, uint32_t n,
                             const double* pts, uint8_t* out) {
-  if (general) hipLaunchKernelGGL((k_points_shadowed<true>), grid_for(n), dim3(BLOCK), lds_bytes, stream, dev, n, pts, out);
-  else hipLaunchKernelGGL((k_points_shadowed<false>), grid_for(n), dim3(BLOCK), lds_bytes, stream, dev, n, pts, out);
+  in_pieces(scene, n, [&](const SceneDev& dev, dim3 grid) {
+    if (general) hipLaunchKernelGGL((k_points_shadowed<true>), grid, dim3(BLOCK), lds_bytes, stream, dev, n, pts, out);
+    else hipLaunchKernelGGL((k_points_shadowed<false>), grid, dim3(BLOCK), lds_bytes, stream, dev, n, pts, out);
+  });
 }
 void launch_pixel_rays(hipStream_t stream, const CameraDev& cam, uint32_t n, const uint32_t* xy, double* rays6) {
   hipLaunchKernelGGL(k_pixel_rays, grid_for(n), dim3(BLOCK), 0, stream, cam, n, xy, rays6);

@@ -119,6 +119,7 @@ struct rt_scene {
   // Shadow queries of hits on a cone's extension, walked by a kernel of their own (scenes with bounded cones)
   bool set_aside = false;
   rt::ShadowBuf aside_buf;
+  void* csg_spill_buf = nullptr;  // SceneDev::csg_spill: CSG hit lists too long for the LDS
   uint32_t* d_counts = nullptr;           // [gen][QUEUE_SEGMENTS]: rays queued for the next generation, per segment
   unsigned long long* d_stats = nullptr;  // STAT_WORDS counters
   uint32_t* h_counts = nullptr;           // pinned mirrors
@@ -196,7 +197,7 @@ inline void copy3x4(double* dst, const double* src16) { memcpy(dst, src16, 12 * 
 // dynamic LDS of a traversal kernel's workgroup: the per-lane stack, then (scenes with CSG operators) the hit list
 inline unsigned traversal_lds_bytes(const rt_scene* s) {
   return (unsigned)s->dev.stack_entries * BLOCK * (unsigned)sizeof(uint32_t) +
-         (s->has_csg ? (unsigned)s->dev.csg_hits * 3u * BLOCK * (unsigned)sizeof(uint32_t) : 0u);
+         (s->has_csg && !s->dev.csg_spill ? (unsigned)s->dev.csg_hits * 3u * BLOCK * (unsigned)sizeof(uint32_t) : 0u);
 }
 
 struct PipelineIn {

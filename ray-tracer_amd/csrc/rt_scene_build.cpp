@@ -412,8 +412,8 @@ struct SceneBuild {
         csg_leaves.push_back(cl);
       }
       R.n_leaves = (uint32_t)csg_leaves.size() - R.first_leaf;
-      if (possible > CSG_MAX_HITS)
-        throw std::length_error("a CSG operator tree whose shapes can yield more than 60 intersections per ray");
+      if (possible > CSG_SPILL_MAX_HITS)
+        throw std::length_error("a CSG operator tree whose shapes can yield more than 4096 intersections per ray");
       csg_hits = std::max(csg_hits, possible);
       const uint32_t root_index = (uint32_t)csg_roots.size();
       csg_roots.push_back(R);
@@ -531,6 +531,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   for (GenBuf& g : s->gens)
     if (g.slab) (void)hipFree(g.slab);
   if (s->aside_buf.slab) (void)hipFree(s->aside_buf.slab);
+  if (s->csg_spill_buf) (void)hipFree(s->csg_spill_buf);
   if (s->d_counts) (void)hipFree(s->d_counts);
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->h_counts) (void)hipHostFree(s->h_counts);
@@ -595,6 +596,24 @@ static int scene_runtime_init(rt_scene* s, int device) {
     HIP_TRY(hipEventCreate(&f.begin));
     HIP_TRY(hipEventCreate(&f.end));
   }
+  return RT_OK;
+}
+
+// Hit lists longer than the LDS holds (SceneDev::csg_hits > CSG_MAX_HITS) live in device memory: one list per
+// workgroup of a launch, as many as fit about a gigabyte (the scene's jobs are then launched in pieces of that
+// many workgroups).  On the current device.
+static int attach_csg_spill(rt_scene* s) {
+  s->dev.csg_spill = nullptr;
+  s->dev.csg_spill_slots = 0;
+  s->dev.first_block = 0;
+  if (s->dev.csg_hits <= CSG_MAX_HITS) return RT_OK;
+  const size_t list_bytes = (size_t)s->dev.csg_hits * 3u * BLOCK * sizeof(uint32_t);
+  size_t slots = ((size_t)1 << 30) / list_bytes;
+  slots = std::min<size_t>(8192, std::max<size_t>(128, slots)) & ~(size_t)127;  // whole runs of the XCD-aware block order
+  HIP_TRY(hipMalloc(&s->csg_spill_buf, slots * list_bytes));
+  s->dev.csg_spill = (uint32_t*)s->csg_spill_buf;
+  s->dev.csg_spill_slots = (uint32_t)slots;
+  s->scene_bytes += slots * list_bytes;
   return RT_OK;
 }
 
@@ -807,6 +826,7 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
   if ((rc = upload(s, b.csg_unbounded, &s->dev.csg_unbounded))) return rc;
   s->dev.n_csg_unbounded = (int32_t)b.csg_unbounded.size();
   s->dev.csg_hits = b.csg_hits;
+  if ((rc = attach_csg_spill(s))) return rc;
   if ((rc = upload(s, b.bands, &s->dev.bands))) return rc;
   {
     std::vector<ConeBandF32> bands32 = cone_bands_f32(b.bands);
@@ -1258,6 +1278,7 @@ static int scene_rebuild(rt_scene* s, const rt_scene_desc* d) {
   std::swap(s->max_children, fresh->max_children);
   std::swap(s->set_aside, fresh->set_aside);
   std::swap(s->host, fresh->host);  // the refit's device arrays travel with their owner
+  std::swap(s->csg_spill_buf, fresh->csg_spill_buf);
   s->build_seconds += fresh->build_seconds;
   s->device_build_seconds += fresh->device_build_seconds;
   s->device_builds += fresh->device_builds;
@@ -1318,6 +1339,11 @@ extern "C" int rt_scene_clone(const rt_scene* src, int device, rt_scene** out) {
     }
     HIP_TRY(hipDeviceSynchronize());
     s->scene_bytes = src->scene_bytes;
+    if (src->dev.csg_spill) {
+      s->scene_bytes -= (size_t)src->dev.csg_spill_slots * src->dev.csg_hits * 3u * BLOCK * sizeof(uint32_t);
+      int rcs = attach_csg_spill(s);
+      if (rcs) return rcs;
+    }
     s->build_seconds = 0;
     s->stack_need = src->stack_need;
     s->has_csg = src->has_csg;

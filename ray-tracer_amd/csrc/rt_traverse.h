@@ -164,22 +164,24 @@ DEV void test_quad(const SceneDev& S, const QuadPrim& q, const Ray& ray, Query& 
 // operators filter their own lists first.  Here all leaf intersections below the root go into one
 // list sorted by (t, leaf order) -- the order every stable sort of the reference yields -- and the
 // operators run innermost first over the entries that are theirs and still alive.
-// The list lives in LDS: entry e of a lane at words (3 e + {0, 1, 2}) * BLOCK: t low, t high, leaf slot.
-template <class Query, class Stack, int BLOCK_>
-DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query& Q, Stack& st, bool outer_gates) {
+// The list lives in LDS: entry e of a lane at words (3 e + {0, 1, 2}) * BLOCK: t low, t high, leaf slot.  SPILL:
+// the scene's lists are longer than the LDS holds; they live in device memory, one per workgroup of the launch,
+// and an entry that an operator filtered out is marked in its leaf-slot word instead of a 64-bit mask.
+template <class Query, class Stack, int BLOCK_, bool SPILL>
+DEV void eval_csg_list(const SceneDev& S, uint32_t root_index, const Ray& ray, Query& Q, uint32_t* list, bool outer_gates) {
   const CsgRoot R = S.csg_roots[root_index];
-  uint32_t* list = st.csg;
   if (!list) return;
   if (outer_gates)
     for (int g = R.gate; g >= 0; g = S.gates[g].parent)
       if (!gate_passes<true>(S, S.gates[g], ray)) return;
+  constexpr uint32_t DEAD = 0x80000000u;
   auto put = [&](int e, double t, uint32_t who) {
     list[(3 * e + 0) * BLOCK_] = (uint32_t)__double2loint(t);
     list[(3 * e + 1) * BLOCK_] = (uint32_t)__double2hiint(t);
     list[(3 * e + 2) * BLOCK_] = who;
   };
   auto get_t = [&](int e) { return __hiloint2double((int)list[(3 * e + 1) * BLOCK_], (int)list[(3 * e + 0) * BLOCK_]); };
-  auto get_who = [&](int e) { return list[(3 * e + 2) * BLOCK_]; };
+  auto get_who = [&](int e) { return list[(3 * e + 2) * BLOCK_] & ~DEAD; };
   int n = 0;
   for (uint32_t j = 0; j < R.n_leaves; j++) {
     const CsgLeaf L = S.csg_leaves[R.first_leaf + j];
@@ -215,13 +217,23 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
     }
   }
   if (n == 0) return;
-  static_assert(CSG_MAX_HITS <= 64, "one bit of `alive` per list entry");
-  unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  static_assert(CSG_MAX_HITS <= 64, "one bit of `alive` per list entry while the list is in LDS");
+  unsigned long long alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);  // !SPILL
+  int n_alive = n;                                                     // SPILL
+  auto is_alive = [&](int e) { return SPILL ? !(list[(3 * e + 2) * BLOCK_] & DEAD) : (bool)((alive >> e) & 1ull); };
+  auto kill = [&](int e) {
+    if constexpr (SPILL) {
+      list[(3 * e + 2) * BLOCK_] |= DEAD;
+      n_alive--;
+    } else {
+      alive &= ~(1ull << e);
+    }
+  };
   for (int c = (int)R.n_nodes - 1; c >= 0; c--) {  // children carry larger indices than their parents
     const int op = S.csg_nodes[R.first_node + c].op;
     bool inl = false, inr = false;
     for (int e = 0; e < n; e++) {
-      if (!((alive >> e) & 1ull)) continue;
+      if (!is_alive(e)) continue;
       const CsgLeaf& L = S.csg_leaves[R.first_leaf + get_who(e)];
       int a = L.node, level = 0;
       while (a > c) {
@@ -236,15 +248,15 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
       else allowed = lhit ? !inr : inl;
       if (lhit) inl = !inl;
       else inr = !inr;
-      if (!allowed) alive &= ~(1ull << e);
+      if (!allowed) kill(e);
     }
   }
-  if (!alive) return;
+  if (SPILL ? n_alive == 0 : alive == 0ull) return;
   for (uint32_t j = 0; j < R.n_leaves; j++) {
     double t[4];
     int m = 0;
     for (int e = 0; e < n; e++)
-      if (((alive >> e) & 1ull) && get_who(e) == j && m < 4) t[m++] = get_t(e);
+      if (is_alive(e) && get_who(e) == j && m < 4) t[m++] = get_t(e);
     if (!m) continue;
     const CsgLeaf L = S.csg_leaves[R.first_leaf + j];
     const uint32_t idx = L.ref & MAX_RUN_FIRST;
@@ -257,6 +269,16 @@ DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query&
     } else {
       Q.leaf_ts(S.quads[idx].leaf, m, t);
     }
+  }
+}
+
+template <class Query, class Stack, int BLOCK_>
+DEV void eval_csg(const SceneDev& S, uint32_t root_index, const Ray& ray, Query& Q, Stack& st, bool outer_gates) {
+  if (S.csg_spill) {  // this workgroup's list (one wave per workgroup): csg_hits entries of 3 x BLOCK words
+    uint32_t* list = S.csg_spill + (size_t)blockIdx.x * (size_t)S.csg_hits * 3u * BLOCK_ + __lane_id();
+    eval_csg_list<Query, Stack, BLOCK_, true>(S, root_index, ray, Q, list, outer_gates);
+  } else {
+    eval_csg_list<Query, Stack, BLOCK_, false>(S, root_index, ray, Q, st.csg, outer_gates);
   }
 }
 

@@ -113,9 +113,11 @@ static_assert(sizeof(Gate) == 192, "Gate layout");
 // tree; a ray that reaches it collects the intersections of all leaves below (at most
 // SceneDev::csg_hits, the most any root of the scene can yield: 2 per sphere or cube, 4 per cylinder or
 // cone, 1 per plane or triangle), sorts them and runs every operator's filter, innermost first.  The list
-// lives in LDS, 768 bytes per entry and wave, beside the 16 KB traversal stack: CSG_MAX_HITS entries fit
-// the 64 KB a workgroup may use.
-constexpr int CSG_MIN_HITS = 16, CSG_MAX_HITS = 60;
+// lives in LDS, 768 bytes per entry and wave, behind the traversal stack: CSG_MAX_HITS entries fit the 64 KB a
+// workgroup may use.  A scene with a root that can yield more keeps its lists in device memory instead
+// (SceneDev::csg_spill: one list per workgroup of a launch, so such scenes are launched in pieces of
+// csg_spill_slots workgroups), up to CSG_SPILL_MAX_HITS entries.
+constexpr int CSG_MIN_HITS = 16, CSG_MAX_HITS = 60, CSG_SPILL_MAX_HITS = 4096;
 struct CsgRoot {
   uint32_t first_leaf, n_leaves;  // into csg_leaves
   uint32_t first_node, n_nodes;   // into csg_nodes, parents before children
@@ -194,6 +196,7 @@ struct SceneDev {
   const CsgNode* csg_nodes;
   const CsgLeaf* csg_leaves;
   const uint32_t* csg_unbounded;  // roots without a finite box: evaluated for every ray
+  uint32_t* csg_spill;            // hit lists in device memory (csg_hits > CSG_MAX_HITS), else null: they live in LDS
   const LeafShade* leaves;
   const XformDev* xforms;
   const TriShade* tri_shade;
@@ -210,8 +213,11 @@ struct SceneDev {
   int32_t n_csg_unbounded;
   int32_t n_inline_planes;
   int32_t band_items16;  // 1: band_items holds uint16_t entries (scenes of fewer than 65536 bounded cones)
-  int32_t csg_hits;      // entries of the per-ray CSG hit list (CSG_MIN_HITS .. CSG_MAX_HITS)
+  int32_t csg_hits;      // entries of the per-ray CSG hit list (at least CSG_MIN_HITS)
   int32_t stack_entries; // entries of the per-lane traversal stack the kernels are launched with (<= TRAVERSAL_STACK)
+  uint32_t csg_spill_slots;  // workgroups one launch of such a scene may have (each owns one list of csg_spill)
+  // first workgroup of this launch among those of the whole job (launches in pieces: 0 otherwise); set per launch
+  uint32_t first_block;
   int32_t stack_pad;
 #ifdef RT_DIAG_NO_BANDS
   int32_t band_diag_passes;  // timing builds only: how many passes of the cone direction index run (0..3)

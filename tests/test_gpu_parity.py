@@ -362,17 +362,74 @@ def test_csg_of_fifteen_cylinders_in_one_hit_list(pkg, root):
     assert np.array_equal(gpu.is_shadowed(rays[:, :3]), cpu.is_shadowed(rays[:, :3]))
 
 
+def test_csg_hit_lists_longer_than_the_lds_holds(pkg, root):
+    """Forty capped cylinders under thirty-nine operators (a balanced tree): 160 possible intersections per ray, more
+    than the 60 a hit list in LDS holds, so the lists live in device memory and the kernels are launched in pieces
+    (the reference has no limit, src/shape.rs:1339-1354).  Image, rays, shadows against the oracle; through rt_render,
+    rt_intersect_hit, rt_color_at and rt_is_shadowed."""
+    import sys
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from scenegen import matmul, rot_x, rot_z, scaling, translation
+
+    leaves = []
+    for k in range(40):
+        turn = rot_z(0.12 * (k % 6)) if k % 2 else rot_x(0.09 * (k % 5))
+        leaves.append({"ty": "capped_cylinder",
+                       "transform": matmul(translation(0.55 * k - 10.7, 0.12 * (k % 3), 0.06 * (k % 4)), matmul(turn, scaling(0.7, 0.9 + 0.1 * (k % 4), 0.7))),
+                       "material": {"color": [0.2 + 0.02 * k, 0.95 - 0.02 * k, 0.4 + 0.01 * (k % 7)], "reflective": 0.25 if k % 5 == 0 else 0.0}})
+
+    def tree(shapes, depth):
+        if len(shapes) == 1:
+            return shapes[0]
+        half = len(shapes) // 2
+        op = "difference" if depth % 3 == 2 else "union"
+        return {"ty": op, "children": [tree(shapes[:half], depth + 1), tree(shapes[half:], depth + 1)]}
+
+    base = json.load(open(os.path.join(root, "scenes", "example.json")))
+    text = json.dumps(dict(base, canvas_width=240, canvas_height=64, camera_from=[0.0, 3.0, -16.0], camera_to=[0.0, 0.0, 0.0],
+                           shapes=[tree(leaves, 0), base["shapes"][1]]))
+    gpu, cpu = pkg.Scene(text, root, device=0), orc.OracleScene(text, root)
+    out, st = gpu.render()
+    want = cpu.render(jobs=8)
+    assert len(np.unique(want["hit_leaf"])) >= 12
+    compare_images(out, st, want, "csg of forty capped cylinders")
+    rng = np.random.default_rng(4)
+    n = 700
+    o = np.stack([rng.uniform(-14.0, -12.0, n), rng.uniform(-0.7, 0.9, n), rng.uniform(-0.5, 0.5, n)], axis=1)
+    o[n // 2:, 0] *= -1.0
+    target = np.stack([-o[:, 0], rng.uniform(-0.7, 0.9, n), rng.uniform(-0.5, 0.5, n)], axis=1)
+    d = target - o
+    rays = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], axis=1)
+    t, leaf = gpu.intersect_hit(rays)
+    wt, wleaf = cpu.intersect_hit(rays)
+    assert (wleaf >= 0).mean() > 0.5
+    assert np.array_equal(leaf, wleaf) and np.array_equal(t[leaf >= 0], wt[leaf >= 0])
+    rgb, _, st2 = gpu.color_at(rays)
+    wrgb, _, counts = cpu.color_at(rays)
+    assert np.abs(rgb - wrgb).max() <= 1e-9 and [st2.primary, st2.shadow, st2.reflect, st2.refract] == counts
+    assert np.array_equal(gpu.is_shadowed(rays[:, :3]), cpu.is_shadowed(rays[:, :3]))
+    # a frame of more workgroups than the scene owns lists: launched in pieces
+    gpu.set_canvas(1200, 500)
+    cpu.set_canvas(1200, 500)
+    big, _ = gpu.render(rgb64=False)
+    ys, xs = np.meshgrid(np.arange(0, 500, 25), np.arange(0, 1200, 15), indexing="ij")
+    sub = cpu.render(jobs=8, x0=0, xstep=15, y0=0, ystep=25)
+    assert np.array_equal(big["hit_leaf"][ys, xs], sub["hit_leaf"][ys, xs])
+
+
 def test_csg_with_too_many_possible_hits_is_refused(pkg, root):
     cyl = {"ty": "capped_cylinder"}
 
     def pair(x):
         return {"ty": "union", "children": [x, x]}
 
-    tree = pair(pair(pair(pair(cyl))))  # 16 cylinders: 64 possible intersections per ray, the list holds 60
+    tree = cyl
+    for _ in range(11):  # 2048 cylinders: 8192 possible intersections per ray, the lists hold 4096
+        tree = pair(tree)
     with pytest.raises(pkg.RtError) as e:
         _csg_world(pkg, root, [tree])
-    assert e.value.status == -2 and "60" in e.value.message
-    _csg_world(pkg, root, [{"ty": "union", "children": [pair(pair(pair(cyl))), pair(pair(cyl))]}])  # 48: accepted
+    assert e.value.status == -2 and "4096" in e.value.message
+    _csg_world(pkg, root, [pair(pair(pair(pair(cyl))))])  # 16 cylinders, 64 possible intersections: accepted
 
 
 def test_parallel_render_writes_the_reference_ppm(pkg, root, tmp_path):
