@@ -713,11 +713,16 @@ static int scene_create_impl(const rt_scene_desc* d, int device, uint32_t build_
   auto t0 = std::chrono::steady_clock::now();
   SceneBuild b;
   b.d = d;
-  {  // where the hierarchy is built: RT_BUILD_DEVICE, or RT_AMD_DEVICE_BVH=1 / 0 in the environment
-    bool on_device = (build_flags & RT_BUILD_DEVICE) != 0;
-    if (const char* e = getenv("RT_AMD_DEVICE_BVH")) on_device = atoi(e) != 0;
+  {  // where the hierarchy is built: large subtrees on the GPU unless the caller or the environment says otherwise
+    bool on_device = (build_flags & RT_BUILD_HOST) == 0;
+    size_t min_items = (build_flags & RT_BUILD_DEVICE) ? 2048 : 32768;
+    if (const char* e = getenv("RT_AMD_DEVICE_BVH")) {
+      on_device = atoi(e) != 0;
+      if (on_device) min_items = 2048;
+    }
+    if (const char* e = getenv("RT_AMD_DEVICE_BVH_MIN")) min_items = (size_t)std::max(2, atoi(e));
     b.bvh.on_device = on_device;
-    if (const char* e = getenv("RT_AMD_DEVICE_BVH_MIN")) b.bvh.device_min_items = (size_t)std::max(2, atoi(e));
+    b.bvh.device_min_items = min_items;
   }
   b.gate_children.resize(d->n_gates);
   b.gate_leaves.resize(d->n_gates);

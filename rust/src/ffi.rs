@@ -41,6 +41,7 @@ pub const RT_FLAG_BANDS_16: u32 = 16;
 pub const RT_FLAG_BANDS_8: u32 = 32;
 // build_flags of rt_scene_create_with
 pub const RT_BUILD_DEVICE: u32 = 1;
+pub const RT_BUILD_HOST: u32 = 2;
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct rt_xform { pub ray_inv: [f64; 16], pub full_inv: [f64; 16], pub fwd: [f64; 16] }
