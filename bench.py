@@ -43,6 +43,17 @@ BYTES_PIXEL = 3
 RECORD_BYTES = 13 * 8 + 4 * 4  # one ray record of a generation buffer
 
 DEPTH = int(os.environ.get("RT_BENCH_DEPTH", "4"))  # frames in flight per GPU = host frames in the ring
+
+
+def ring_depth(parts):
+    """Frames in flight per GPU.  A quarter or an eighth of the frame is one round of waves, so its launch lasts as
+    long as its slowest wave whatever else the GPU could do: only more launches in flight fill it (tools/part_period.py,
+    one GPU rendering its part of N: 0.0534 -> 0.0449 ms per frame at N = 4 and 0.0433 -> 0.0340 at N = 8 with eight
+    instead of four).  Whole and half frames are bound by their copies, and eight host frames of 6.2 MB fall out of the
+    host's last-level cache (0.124 -> 0.160 ms per frame at N = 1)."""
+    if "RT_BENCH_DEPTH" in os.environ:
+        return DEPTH
+    return 8 if parts >= 4 else 4
 # Untimed frames before the warmup, as a stretch of their own that ends with every GPU idle.  A fresh process pays
 # about 20 ms once: code objects and runtime pools with the first launches, and about 5.6 ms for each of three DMA
 # engines on that engine's first copy -- the runtime turns to a second and third engine only when a copy finds the
@@ -167,7 +178,8 @@ def bench_single_process(args, timed=None):
     t_load = time.perf_counter()
     scene = pkg.Scene.from_file(args.scene, base_dir=ROOT, device=None)  # host side only; the loop owns the GPU copies
     scene.set_canvas(W, H)
-    loop = scene.frame_loop(devices, depth=DEPTH)
+    depth = ring_depth(n)
+    loop = scene.frame_loop(devices, depth=depth)
     load_s = time.perf_counter() - t_load
     info, linfo = scene.info(), loop.info()
 
@@ -187,7 +199,7 @@ def bench_single_process(args, timed=None):
         sha, hbm_s = None, None
     else:
         host_s, host_stats = leg(True)
-        last_slot = (args.steps - 1) % DEPTH if timed is not None else (args.warmup + args.steps - 1) % DEPTH
+        last_slot = (args.steps - 1) % depth if timed is not None else (args.warmup + args.steps - 1) % depth
         frame = loop.host_frame(last_slot).copy()
         sha = hashlib.sha256(frame.tobytes()).hexdigest()
         hbm_s = None if args.no_hbm_leg else leg(False)[0]
@@ -304,7 +316,7 @@ def bench_single_process(args, timed=None):
         "PCIe_GBps": W * H * 3 * args.steps / host_s / 1e9,
         "breakdown_ms": {"frame": host_s / args.steps * 1e3, "generation_kernels_per_frame": piped["kernel_ms"] / args.steps,
                          "lone_frame_kernel": lone["kernel_ms"] / 10},
-        "pipeline": {"frames_in_flight_per_gpu": DEPTH, "untimed_priming_frames": PRIMING},
+        "pipeline": {"frames_in_flight_per_gpu": depth, "untimed_priming_frames": PRIMING},
         "frame_sha256": sha,
         "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": linfo["build_seconds"], "scene_bytes": linfo["scene_bytes"],
                   "bvh_builds": 1},
