@@ -7,16 +7,16 @@ tag=${1:-round}
 O=gpurun_out/$tag
 rm -rf $O && mkdir -p $O
 export TMPDIR=/tmp
-B="--steps 20 --warmup 5"  # 256 priming + 5 warm-up launches precede the 20 timed ones: launches 261..280
+B="--steps 20 --warmup 5"  # 32 priming + 5 warm-up launches precede the 20 timed ones: launches 38..57
 timeout -k 10 200 python -u -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { echo "smoke failed"; tail -20 $O/smoke.log; exit 1; }
 tail -1 $O/smoke.log
 timeout -k 10 300 python -u bench.py $B > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -20 $O/bench.err; exit 1; }
 # the loop that leaves the frames in HBM, alone: under rocprofv3 the runtime turns the DMA copies of the metric's
 # loop into copy kernels that share the GPU with the render kernel, so that loop is traced separately below
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_hbm -- python3 bench.py $B --no-cpu-baseline --hbm-only > $O/trace_hbm_bench.json 2> $O/trace_hbm.err || { echo "rocprof (hbm) failed"; tail -20 $O/trace_hbm.err; exit 1; }
-python3 tools/timeline.py $O/trace_hbm 261 20 > $O/timeline_hbm.txt || exit 1
+python3 tools/timeline.py $O/trace_hbm 38 20 > $O/timeline_hbm.txt || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_host -- python3 bench.py $B --no-cpu-baseline --no-hbm-leg > $O/trace_host_bench.json 2> $O/trace_host.err || { echo "rocprof (host) failed"; tail -20 $O/trace_host.err; exit 1; }
-python3 tools/timeline.py $O/trace_host 261 20 > $O/timeline_host.txt || exit 1
+python3 tools/timeline.py $O/trace_host 38 20 > $O/timeline_host.txt || exit 1
 P="--steps 3 --warmup 1 --no-cpu-baseline --hbm-only"
 pass() {  # name, counters
   timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $O/pmc/$1 -- python3 bench.py $P > $O/pmc_$1.out 2> $O/pmc_$1.err || { echo "pmc pass $1 failed"; tail -5 $O/pmc_$1.err; exit 1; }
@@ -36,7 +36,9 @@ for t in trace_hbm trace_host; do f=$(find $O/$t -name "*kernel_stats.csv" -prin
 rm -rf $O/trace_hbm $O/trace_host $O/pmc $O/pmc_traffic
 ls $O
 # what one GPU of an N-GPU run does (part 0..N-1 of N alone on this GPU), copy rates, host registration
-timeout -k 10 200 python3 tools/part_period.py > $O/part_period.txt 2>&1 || { echo "part_period failed"; exit 1; }
+timeout -k 10 300 python3 tools/part_period.py > $O/part_period.txt 2>&1 || { echo "part_period failed"; exit 1; }
+# the same with eight frames in flight (what bench.py uses for four parts or more), bands of 8 rows
+timeout -k 10 200 python3 tools/part_period.py 8 8 > $O/part_period_depth8.txt 2>&1 || { echo "part_period (depth 8) failed"; exit 1; }
 if [ -x ray-tracer_amd/lib/d2h_probe ]; then timeout -k 10 100 ray-tracer_amd/lib/d2h_probe > $O/d2h_probe.txt 2>&1 || exit 1; fi
 if [ -x ray-tracer_amd/lib/register_probe ]; then timeout -k 10 100 ray-tracer_amd/lib/register_probe > $O/register_probe.txt 2>&1 || exit 1; fi
 # the launcher path, two ranks on this one GPU (gloo for the barriers): a rehearsal, no scaling figure

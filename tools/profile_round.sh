@@ -5,10 +5,12 @@
 # index's resolution table, its pass-by-pass timing (diagnostic build) and the phase shares with the band hits
 # used and dropped.  Needs `make -C ray-tracer_amd all diag probes lib/librt_host_nobands.so lib/librt_host_stamps.so`.
 # usage: tools/profile_round.sh [tag]      results under gpurun_out/<tag>/
+# RT_PROFILE_SKIP_ROUND=1: tools/gpu_round.sh <tag> ran in a call of its own (together they can exceed one call's limit)
 set -o pipefail
 tag=${1:-profile}
-bash tools/gpu_round.sh $tag || exit 1
+if [ -z "$RT_PROFILE_SKIP_ROUND" ]; then bash tools/gpu_round.sh $tag || exit 1; fi
 O=gpurun_out/$tag
+mkdir -p $O
 timeout -k 10 300 python -u bench.py > $O/bench_final_tree.json 2> $O/bench_final_tree.err || exit 1
 bash tools/pmc_configs.sh $tag teapot glass heightfield primitives > $O/pmc_configs.log 2>&1 || { tail -20 $O/pmc_configs.log; exit 1; }
 timeout -k 10 600 python -u tools/bench_configs.py --counters > $O/configs.jsonl 2>>$O/err.log || exit 1
