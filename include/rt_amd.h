@@ -279,8 +279,16 @@ int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, u
 
 /* Frames of a render loop, back to back.  With RT_FLAG_ASYNC, rt_render enqueues the frame on the
  * scene's stream and returns at once (stats is not written); at most eight frames are in flight, a
- * ninth call waits for the oldest.  A scene whose materials spawn reflection or refraction rays
- * needs the host between generations, so there the call blocks as usual (its counts still go to rt_scene_wait).
+ * ninth call waits for the oldest.  A scene whose materials spawn reflection or refraction rays is a
+ * row of ray generations: its first frame for a camera size and depth is rendered one generation at a
+ * time (the call blocks, its counts still go to rt_scene_wait); later frames launch every generation at
+ * once on the queue lengths of the last frame and are only enqueued, up to four in flight.  Whether such
+ * a frame's queues had room is known when its counters are back, and the library looks at them before
+ * anything reads the frame: in rt_download / rt_download_2d of its image (which therefore wait for that
+ * frame, not for the frames enqueued after it), in rt_scene_wait and in every blocking entry point.  A
+ * frame that did not fit is rendered again there, exactly, into the same buffers.  A caller keeps such a
+ * GPU busy by enqueuing frame k + 1 before it downloads frame k; work it enqueues itself on the frame's
+ * buffers needs rt_scene_wait first.
  * rt_scene_wait blocks until every enqueued frame is complete and returns the sums of their ray
  * counts, kernel time and kernel launches since the previous wait (render_ms is not filled).
  * Asynchronous frames go round-robin to three streams of the scene.  rt_download / rt_download_2d without

@@ -195,6 +195,15 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
     valid += (uint64_t)w * h;
   }
   if ((flags & RT_FLAG_ASYNC) && s->max_children == 0) return enqueue_direct_frame(s, in, valid);
+  if (flags & RT_FLAG_ASYNC) {  // a scene that spawns rays: every generation at once, verified later, when it can be
+    bool enqueued = false;
+    int rce = enqueue_speculative_frame(s, in, valid, &enqueued);
+    if (rce) return rce;
+    if (enqueued) {
+      s->last_stream = s->stream;
+      return RT_OK;
+    }
+  }
   int rc = collect_all(s);  // frames still in flight finish first
   if (rc) return rc;
   s->last_stream = s->stream;
@@ -309,7 +318,10 @@ extern "C" int rt_download_2d(rt_scene* s, const void* src_dev, void* dst_host, 
   if (row_bytes == 0 || rows == 0) return RT_OK;
   int rcp = prime_copy_engines(s->device);
   if (rcp) return rcp;
-  int rco = order_copy_stream(s, after_stream);
+  bool finished = false;  // the source is the image of a frame whose end the host has just seen: nothing to order after
+  int rcv = verify_frames(s, src_dev, &finished);
+  if (rcv) return rcv;
+  int rco = finished ? RT_OK : order_copy_stream(s, after_stream);
   if (rco) return rco;
   HIP_TRY(hipMemcpy2DAsync(dst_host, pitch, src_dev, pitch, row_bytes, rows, hipMemcpyDeviceToHost, s->copy_stream));
   return RT_OK;
@@ -321,7 +333,10 @@ extern "C" int rt_download(rt_scene* s, const void* src_dev, void* dst_host, uin
   if (bytes == 0) return RT_OK;
   int rcp = prime_copy_engines(s->device);
   if (rcp) return rcp;
-  int rco = order_copy_stream(s, after_stream);
+  bool finished = false;
+  int rcv = verify_frames(s, src_dev, &finished);
+  if (rcv) return rcv;
+  int rco = finished ? RT_OK : order_copy_stream(s, after_stream);
   if (rco) return rco;
   // a plain asynchronous copy: the runtime moves it with a DMA engine, which leaves the compute units
   // to the frame that renders meanwhile (a copy kernel of our own measured 40 % slower frames)

@@ -141,6 +141,10 @@ static int collect_frame(rt_scene* s, rt_scene::FrameSlot& f) {
 
 // Waits for every asynchronous frame, then reads and clears the counters they added to.
 int collect_all(rt_scene* s) {
+  {
+    int rc = verify_frames(s, nullptr, nullptr);
+    if (rc) return rc;
+  }
   for (int k = 0; k < rt_scene::FRAME_SLOTS; k++) {
     int rc = collect_frame(s, s->slots[(s->next_slot + k) % rt_scene::FRAME_SLOTS]);
     if (rc) return rc;
@@ -286,29 +290,38 @@ static int plan_speculative(rt_scene* s, const PipelineIn& in, int max_gen, GenP
   return RT_OK;
 }
 
-static int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_stats* stats, bool* fits) {
-  GenPlan plan(s->depth);
+// Enqueues every generation of the frame, the resolves and the copies of the counters into h_counts / h_stats
+// (pinned); begin / end are recorded around the generation kernels.
+static int launch_speculative(rt_scene* s, const PipelineIn& in, int max_gen, GenPlan& plan, hipEvent_t begin, hipEvent_t end,
+                              uint32_t* h_counts, unsigned long long* h_stats) {
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
+  HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * count_words(s->depth) * sizeof(uint32_t), main_stream(s)));
   int last = 0, rc;
   if ((rc = plan_speculative(s, in, max_gen, plan, &last))) return rc;
-  HIP_TRY(hipEventRecord(s->ev[0], main_stream(s)));
+  HIP_TRY(hipEventRecord(begin, main_stream(s)));
   for (int g = 0; g <= last; g++) {
     GenLaunch a;
     fill_launch(s, in, plan, g, max_gen, a);
     launch_generation(s, (g == 0 && in.camera) ? 1 : 2, false, a);
   }
-  HIP_TRY(hipEventRecord(s->ev[1], main_stream(s)));
+  HIP_TRY(hipEventRecord(end, main_stream(s)));
   launch_resolves(s, in, plan, last);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, count_words(s->depth) * sizeof(uint32_t), hipMemcpyDeviceToHost, main_stream(s)));
-  HIP_TRY(hipMemcpyAsync(s->h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                         main_stream(s)));
-  HIP_TRY(hipStreamSynchronize(main_stream(s)));
+  HIP_TRY(hipMemcpyAsync(h_counts, s->d_counts, count_words(s->depth) * sizeof(uint32_t), hipMemcpyDeviceToHost, main_stream(s)));
+  HIP_TRY(hipMemcpyAsync(h_stats, s->d_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, main_stream(s)));
+  return RT_OK;
+}
+
+// With the counters back: did every queue segment have room for the rays it received?  If so the counts become
+// the next frame's hints and the statistics are filled in.
+static int check_speculative(rt_scene* s, int max_gen, const uint32_t* segcap, const uint32_t* h_counts,
+                             const unsigned long long* h_stats, hipEvent_t begin, hipEvent_t end, rt_stats* stats, bool* fits) {
   *fits = true;
   int true_last = 0;
   for (int g = 1; g <= max_gen && *fits; g++) {  // counters [g - 1]: the rays queued for generation g
     uint32_t fullest = 0;
-    for (int k = 0; k < QUEUE_SEGMENTS; k++) fullest = std::max(fullest, s->h_counts[(g - 1) * QUEUE_SEGMENTS + k]);
-    if (fullest > plan.segcap[g]) *fits = false;
+    for (int k = 0; k < QUEUE_SEGMENTS; k++) fullest = std::max(fullest, h_counts[(g - 1) * QUEUE_SEGMENTS + k]);
+    if (fullest > segcap[g]) *fits = false;
     if (fullest == 0) break;
     true_last = g;
   }
@@ -316,13 +329,13 @@ static int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_st
   for (int g = 1; g <= s->depth + 2; g++) {
     uint32_t fullest = 0;
     if (g <= true_last)
-      for (int k = 0; k < QUEUE_SEGMENTS; k++) fullest = std::max(fullest, s->h_counts[(g - 1) * QUEUE_SEGMENTS + k]);
+      for (int k = 0; k < QUEUE_SEGMENTS; k++) fullest = std::max(fullest, h_counts[(g - 1) * QUEUE_SEGMENTS + k]);
     s->hint[g] = fullest;
   }
   if (stats) {
-    decode_stats(s->h_stats, stats);
+    decode_stats(h_stats, stats);
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms, begin, end));
     stats->kernel_ms = ms;
     stats->kernel_launches = (uint64_t)true_last + 1;
     stats->generations = (uint64_t)true_last + 1;
@@ -330,9 +343,116 @@ static int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_st
   return RT_OK;
 }
 
+static int run_speculative(rt_scene* s, const PipelineIn& in, int max_gen, rt_stats* stats, bool* fits) {
+  GenPlan plan(s->depth);
+  int rc;
+  if ((rc = launch_speculative(s, in, max_gen, plan, s->ev[0], s->ev[1], s->h_counts, s->h_stats))) return rc;
+  HIP_TRY(hipStreamSynchronize(main_stream(s)));
+  return check_speculative(s, max_gen, plan.segcap.data(), s->h_counts, s->h_stats, s->ev[0], s->ev[1], stats, fits);
+}
+
+static bool speculation_off() {
+  static const bool off = getenv("RT_AMD_NO_SPECULATION") != nullptr;
+  return off;
+}
+static bool hints_match(const rt_scene* s, const PipelineIn& in) {
+  return s->hint_valid && s->hint_key[0] == in.n0 && s->hint_key[1] == (uint32_t)in.remaining0;
+}
+// a frame that did not fit is rendered twice, and a camera that moves this fast will do it again: exact for a while
+static void hold_off(rt_scene* s) {
+  s->holdoff = s->holdoff_next;
+  s->holdoff_next = std::min(2 * s->holdoff_next, 64u);
+  static const bool debug = getenv("RT_AMD_DEBUG") != nullptr;
+  if (debug) fprintf(stderr, "[rt_amd] speculative frame did not fit; exact for the next %u frames\n", s->holdoff);
+}
+
+static int run_pipeline_impl(rt_scene* s, const PipelineIn& in, rt_stats* stats, bool exact);
+
+int enqueue_speculative_frame(rt_scene* s, const PipelineIn& in, uint64_t primary, bool* enqueued) {
+  *enqueued = false;
+  const int max_gen = std::max(in.remaining0, 0);
+  static const bool off = getenv("RT_AMD_NO_ASYNC_GENERATIONS") != nullptr;
+  if (off || speculation_off() || s->max_children == 0 || max_gen == 0 || (in.flags & RT_FLAG_COUNTERS) || !in.camera) return RT_OK;
+  if (std::max(max_gen, RECURSION_DEPTH) > s->depth || !hints_match(s, in) || s->holdoff > 0) return RT_OK;
+  if (s->spec_count == rt_scene::SPEC_SLOTS) {  // the oldest makes room; it may turn out not to have fitted
+    int rc = verify_frames(s, s->spec[s->spec_first].in.img.rgb8 ? (const void*)s->spec[s->spec_first].in.img.rgb8
+                                                                    : (const void*)&s->spec[s->spec_first], nullptr);
+    if (rc) return rc;
+    if (s->spec_count == rt_scene::SPEC_SLOTS || !hints_match(s, in) || s->holdoff > 0) return RT_OK;
+  }
+  rt_scene::SpecFrame& f = s->spec[(s->spec_first + s->spec_count) % rt_scene::SPEC_SLOTS];
+  if (!f.begin) {
+    HIP_TRY(hipEventCreate(&f.begin));
+    HIP_TRY(hipEventCreate(&f.end));
+    HIP_TRY(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&f.h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  if (f.counts_depth != s->depth) {
+    if (f.h_counts) HIP_TRY(hipHostFree(f.h_counts));
+    f.h_counts = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&f.h_counts, count_words(s->depth) * sizeof(uint32_t), hipHostMallocDefault));
+    f.counts_depth = s->depth;
+  }
+  GenPlan plan(s->depth);
+  int rc = launch_speculative(s, in, max_gen, plan, f.begin, f.end, f.h_counts, f.h_stats);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(f.done, main_stream(s)));
+  f.in = in;
+  f.max_gen = max_gen;
+  f.segcap = plan.segcap;
+  f.primary = primary;
+  s->spec_count++;
+  *enqueued = true;
+  return RT_OK;
+}
+
+// Does the frame write to this device address?
+static bool frame_holds(const rt_scene::SpecFrame& f, const void* p) {
+  const size_t pixels = (size_t)f.in.cam.hsize * f.in.cam.vsize;
+  auto within = [&](const void* base, size_t bytes) {
+    return base && (const char*)p >= (const char*)base && (const char*)p < (const char*)base + bytes;
+  };
+  return within(f.in.img.rgb8, pixels * 3) || within(f.in.img.rgb64, pixels * 3 * sizeof(double)) ||
+         within(f.in.img.hit_leaf, pixels * sizeof(int32_t)) || p == (const void*)&f;
+}
+
+int verify_frames(rt_scene* s, const void* touching, bool* was_frame) {
+  if (was_frame) *was_frame = false;
+  int upto = s->spec_count;
+  if (touching) {
+    upto = 0;
+    for (int k = 0; k < s->spec_count; k++)
+      if (frame_holds(s->spec[(s->spec_first + k) % rt_scene::SPEC_SLOTS], touching)) upto = k + 1;
+    if (upto > 0 && was_frame) *was_frame = true;
+  }
+  for (int k = 0; k < upto; k++) {
+    rt_scene::SpecFrame& f = s->spec[s->spec_first];
+    s->spec_first = (s->spec_first + 1) % rt_scene::SPEC_SLOTS;
+    s->spec_count--;
+    HIP_TRY(hipEventSynchronize(f.done));
+    rt_stats one{};
+    bool fits = false;
+    int rc = check_speculative(s, f.max_gen, f.segcap.data(), f.h_counts, f.h_stats, f.begin, f.end, &one, &fits);
+    if (rc) return rc;
+    if (fits) {
+      s->holdoff_next = 1;
+    } else {  // again, one generation at a time, into the same buffers (behind whatever was enqueued after it)
+      hold_off(s);
+      if ((rc = run_pipeline_impl(s, f.in, &one, true))) return rc;
+    }
+    rt_stats& t = s->async_total;
+    t.primary += f.primary;
+    t.shadow += one.shadow; t.reflect += one.reflect; t.refract += one.refract;
+    t.kernel_ms += one.kernel_ms; t.kernel_launches += one.kernel_launches; t.generations += one.generations;
+  }
+  return RT_OK;
+}
+
 // Runs the generations, resolves colours back into generation 0 and, for camera
 // rays, writes the image.  Fills the device-side fields of stats.
-int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
+int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) { return run_pipeline_impl(s, in, stats, false); }
+
+static int run_pipeline_impl(rt_scene* s, const PipelineIn& in, rt_stats* stats, bool exact) {
   const bool count = (in.flags & RT_FLAG_COUNTERS) != 0;
   int max_gen = std::max(in.remaining0, 0);  // World::color_at recurses `remaining` levels (src/world.rs:146, 185, 249)
   if (s->max_children == 0) max_gen = 0;
@@ -341,14 +461,13 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
     if (rcd) return rcd;
   }
   const bool direct = in.camera && max_gen == 0;  // every pixel is final after generation 0
-  static const bool no_speculation = getenv("RT_AMD_NO_SPECULATION") != nullptr;
-  const bool hinted = max_gen > 0 && !count && !no_speculation && s->hint_valid && s->hint_key[0] == in.n0 &&
-                      s->hint_key[1] == (uint32_t)in.remaining0;
-  if (hinted && s->holdoff > 0) {
+  const bool no_speculation = speculation_off();
+  const bool hinted = max_gen > 0 && !count && !no_speculation && hints_match(s, in);
+  if (hinted && exact) {
+    if (s->holdoff > 0) s->holdoff--;
+  } else if (hinted && s->holdoff > 0) {
     s->holdoff--;
   } else if (hinted) {
-    HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
-    HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * count_words(s->depth) * sizeof(uint32_t), main_stream(s)));
     bool fits = false;
     int rc = run_speculative(s, in, max_gen, stats, &fits);
     if (rc) return rc;
@@ -356,12 +475,7 @@ int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) {
       s->holdoff_next = 1;
       return RT_OK;
     }
-    // start over, one generation at a time, and stay exact for a while: a frame that does not fit is
-    // rendered twice, and a camera that moves this fast will do it again
-    s->holdoff = s->holdoff_next;
-    s->holdoff_next = std::min(2 * s->holdoff_next, 64u);
-    static const bool debug = getenv("RT_AMD_DEBUG") != nullptr;
-    if (debug) fprintf(stderr, "[rt_amd] speculative frame did not fit; exact for the next %u frames\n", s->holdoff);
+    hold_off(s);  // start over, one generation at a time, and stay exact for a while
   }
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_WORDS * sizeof(unsigned long long), main_stream(s)));
   if (max_gen > 0 || s->set_aside) HIP_TRY(hipMemsetAsync(s->d_counts, 0, 2 * count_words(s->depth) * sizeof(uint32_t), main_stream(s)));

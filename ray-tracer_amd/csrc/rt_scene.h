@@ -60,6 +60,18 @@ inline void carve(ShadowBuf& b) {
   v.target = (uint32_t*)(d + 6 * c);
 }
 
+// What one frame (or one batch of caller rays) asks of the pipeline.
+struct PipelineIn {
+  uint32_t n0 = 0;
+  int remaining0 = RECURSION_DEPTH;
+  uint32_t flags = 0;
+  bool camera = false;  // generation 0 from the camera (else from gens[0] ray arrays)
+  CameraDev cam{};
+  const uint32_t* tiles = nullptr;
+  uint32_t tiles_x = 0;
+  ImageOut img{nullptr, nullptr, nullptr, 0};
+};
+
 }  // namespace rt
 
 struct rt_scene {
@@ -145,6 +157,24 @@ struct rt_scene {
   FrameSlot slots[FRAME_SLOTS];
   int next_slot = 0;
   rt_stats async_total{};
+  // Frames of a scene that spawns rays, enqueued under RT_FLAG_ASYNC with every generation launched at once on the
+  // queue lengths of the last verified frame.  Whether such a frame fitted its queues is known when its counters
+  // are back; until then it is unverified, and one that did not fit is rendered again, exactly, into the same
+  // buffers before anything reads them (rt::verify_frames: downloads of its images, rt_scene_wait, the next
+  // blocking call).  A short queue, oldest first.
+  struct SpecFrame {
+    rt::PipelineIn in;
+    int max_gen = 0;
+    std::vector<uint32_t> segcap;  // record slots per queue segment the generations were launched with
+    uint64_t primary = 0;
+    hipEvent_t begin = nullptr, end = nullptr, done = nullptr;  // around the generation kernels; after the counters' copies
+    uint32_t* h_counts = nullptr;  // pinned: this frame's queue counters and statistics
+    unsigned long long* h_stats = nullptr;
+    int counts_depth = -1;         // recursion depth h_counts was sized for
+  };
+  static constexpr int SPEC_SLOTS = 4;
+  SpecFrame spec[SPEC_SLOTS];
+  int spec_first = 0, spec_count = 0;
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -187,7 +217,10 @@ std::string& last_error_text();
 int attach_band_grid(rt_scene* s, size_t n_bands);
 void world_normal(const double* full_inv, const double* local_normal, double* out);  // of a plane or flat triangle
 // rt_pipeline.cpp
-int collect_all(rt_scene* s);  // waits for the frames in flight, then reads and clears the counters they added to
+int collect_all(rt_scene* s);  // waits for the frames in flight (verifying those that need it), then reads and clears the counters they added to
+// Verifies the unverified frames, oldest first: all of them, or (touching != nullptr) those up to the last one whose
+// image buffers hold that device address; *was_frame tells whether one did.
+int verify_frames(rt_scene* s, const void* touching, bool* was_frame);
 int ensure_gen(rt_scene* s, int g, size_t cap);
 int ensure_depth(rt_scene* s, int depth);  // buffers, counters and events for a recursion that deep
 int ensure_aside(rt_scene* s, uint32_t rays);  // room for the shadow queries a generation of that many rays may set aside
@@ -200,21 +233,14 @@ inline unsigned traversal_lds_bytes(const rt_scene* s) {
          (s->has_csg && !s->dev.csg_spill ? (unsigned)s->dev.csg_hits * 3u * BLOCK * (unsigned)sizeof(uint32_t) : 0u);
 }
 
-struct PipelineIn {
-  uint32_t n0 = 0;
-  int remaining0 = RECURSION_DEPTH;
-  uint32_t flags = 0;
-  bool camera = false;  // generation 0 from the camera (else from gens[0] ray arrays)
-  CameraDev cam{};
-  const uint32_t* tiles = nullptr;
-  uint32_t tiles_x = 0;
-  ImageOut img{nullptr, nullptr, nullptr, 0};
-};
 CameraDev camera_dev(const rt_camera* c);
 // Runs the generations, resolves colours back into generation 0 and, for camera rays, writes the image.
 int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats);
 // One camera frame of a scene that spawns no rays: a single kernel, only enqueued.
 int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary);
+// One camera frame of a scene that spawns rays, only enqueued: possible when the last frame's queue lengths are
+// known for this job (*enqueued; otherwise the caller renders it with run_pipeline).
+int enqueue_speculative_frame(rt_scene* s, const PipelineIn& in, uint64_t primary, bool* enqueued);
 
 }  // namespace rt
 

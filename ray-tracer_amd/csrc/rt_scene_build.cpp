@@ -548,6 +548,12 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   for (rt_scene::FrameSlot& f : s->slots)
     for (hipEvent_t e : {f.begin, f.end})
       if (e) (void)hipEventDestroy(e);
+  for (rt_scene::SpecFrame& f : s->spec) {
+    for (hipEvent_t e : {f.begin, f.end, f.done})
+      if (e) (void)hipEventDestroy(e);
+    if (f.h_counts) (void)hipHostFree(f.h_counts);
+    if (f.h_stats) (void)hipHostFree(f.h_stats);
+  }
   if (s->copy_stream) {
     (void)hipStreamSynchronize(s->copy_stream);
     (void)hipStreamDestroy(s->copy_stream);

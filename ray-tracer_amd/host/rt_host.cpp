@@ -1194,6 +1194,7 @@ FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector
   try {
     FlatWorld flat = flatten(world);
     rt_scene_desc desc = flat.desc();
+    for (const rt_material& m : flat.materials) spawns_ = spawns_ || m.reflective != 0.0 || m.transparency != 0.0;
     scenes_.assign(devices.size(), nullptr);
     check_rt(rt_scene_create(&desc, devices[0], &scenes_[0]));
     check_rt(rt_scene_footprint(scenes_[0], nullptr, &build_seconds_));
@@ -1263,13 +1264,19 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     std::vector<int> fenced_by((size_t)depth_, -1);  // per slot: the slot whose fence covers this slot's last copy
     std::vector<int> unfenced;                        // slots copied since the last fence
     size_t last_frame = 0;                            // of the stretch of frames being enqueued
-    auto frame = [&](size_t f) {
+    auto render_part = [&](size_t f) {
       if (!ok) return;
       const int slot = (int)(f % (size_t)depth_);
       uint8_t* dev = dev_frames_[k][(size_t)slot];
       // the copy that last read this device frame (depth frames ago) must be through before it is rendered over
       if (to_host && fenced_by[(size_t)slot] >= 0 && rt_copy_wait(sc, (uint32_t)fenced_by[(size_t)slot]) != RT_OK) ok = false;
       if (ok && rt_render(sc, &cam_, (int)part, (int)n, RT_FLAG_ASYNC | part_flags, dev, nullptr, nullptr, nullptr) != RT_OK) ok = false;
+      if (!ok) errors[k] = rt_last_error();
+    };
+    auto copy_part = [&](size_t f) {
+      if (!ok || !to_host) return;
+      const int slot = (int)(f % (size_t)depth_);
+      uint8_t* dev = dev_frames_[k][(size_t)slot];
       auto fence = [&]() {  // after this slot's copy has been enqueued
         unfenced.push_back(slot);
         if (unfenced.size() < stride && f != last_frame) return;
@@ -1277,10 +1284,10 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
         for (int s : unfenced) fenced_by[(size_t)s] = slot;
         unfenced.clear();
       };
-      if (ok && to_host && n == 1) {  // the whole frame is this part's: one contiguous copy
+      if (n == 1) {  // the whole frame is this part's: one contiguous copy
         if (rt_download(sc, dev, host_[(size_t)slot], frame_bytes_, nullptr) != RT_OK) ok = false;
         if (ok) fence();
-      } else if (ok && to_host) {
+      } else {
         // this part's bands: whole bands with one strided copy, a last partial band with a plain one
         const size_t first = part * band, n_bands_mine = first < rows_total ? (rows_total - first + n * band - 1) / (n * band) : 0;
         size_t whole = n_bands_mine;
@@ -1296,8 +1303,21 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
       }
       if (!ok) errors[k] = rt_last_error();
     };
+    // A frame of a scene that spawns rays is enqueued unverified (whether its ray queues had room is known when
+    // its counters are back), and a download of its image waits for that.  Its copy is therefore asked for after
+    // the next frame has been enqueued, so the GPU has work while the host looks at the counters; the frames of
+    // other scenes need no such look and are copied as soon as they are enqueued.
+    const bool copy_one_late = spawns_ && to_host && depth_ >= 2;
+    auto stretch = [&](size_t first_f, size_t count) {
+      for (size_t f = first_f; f < first_f + count; f++) {
+        render_part(f);
+        if (!copy_one_late) copy_part(f);
+        else if (f > first_f) copy_part(f - 1);
+      }
+      if (copy_one_late && count > 0) copy_part(first_f + count - 1);
+    };
     last_frame = warmup ? warmup - 1 : 0;
-    for (size_t f = 0; f < warmup; f++) frame(f);
+    stretch(0, warmup);
     rt_stats st{};
     if (ok && rt_scene_wait(sc, &st) != RT_OK) {
       ok = false;
@@ -1306,7 +1326,7 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     meet.arrive_and_wait();  // every GPU idle, every worker ready
     if (k == 0) t0 = std::chrono::steady_clock::now();
     last_frame = warmup + frames - 1;
-    for (size_t f = 0; f < frames; f++) frame(warmup + f);
+    stretch(warmup, frames);
     if (ok && rt_scene_wait(sc, &result.part[k]) != RT_OK) {  // rendered and, with to_host, on the host
       ok = false;
       errors[k] = rt_last_error();

@@ -187,6 +187,7 @@ class FrameLoop {
   // over the parts (teapot 1080p over 8 parts: the fullest part carries 1.08 times the rays of the emptiest with
   // bands of 8 rows, 1.29 times with 32) and one strided copy still moves a part
   size_t band_rows_ = 8;
+  bool spawns_ = false;  // some material reflects or refracts: a frame is several generations of rays
   uint32_t band_flags() const;
 
  public:

@@ -174,14 +174,15 @@ def test_enqueued_frames_equal_blocking_frames(pkg, root):
         assert np.array_equal(b.cpu().numpy(), want["rgb8"])
     again = gpu.wait()  # nothing in flight: zeros
     assert again.kernel_launches == 0 and again.primary == 0
-    # a scene that spawns rays needs the host between generations: the call blocks, and its counts are
-    # reported by rt_scene_wait like those of frames that were only enqueued
+    # a scene that spawns rays: its frames are enqueued too once a first frame has left its queue lengths (every
+    # generation launched at once, verified by rt_scene_wait here; tests/test_gpu_async.py has the other cases)
     glass, _ = load_pair(pkg, root, "glass", (64, 36))
     ref8, st = glass.render(rgb64=False, hit_leaf=False)
     buf = torch.zeros((36, 64, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
     glass.render_device(rgb8_ptr=buf.data_ptr(), wait=False)
-    assert np.array_equal(buf.cpu().numpy(), ref8["rgb8"])  # complete when the call returns
     total = glass.wait()
+    assert np.array_equal(buf.cpu().numpy(), ref8["rgb8"])
     assert (total.primary, total.shadow, total.reflect, total.refract) == (st.primary, st.shadow, st.reflect, st.refract)
     assert total.kernel_launches == st.kernel_launches
 
