@@ -9,8 +9,29 @@
 
 using namespace rt;
 
+// Releases what the lane not in use holds on the device (its stream stays).
+static int release_other_lane(rt_scene* s) {
+  rt_scene::Lane& o = s->other_lane;
+  if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
+  for (GenBuf& g : o.gens)
+    if (g.slab) HIP_TRY(hipFree(g.slab));
+  o.gens.clear();
+  if (o.aside_buf.slab) HIP_TRY(hipFree(o.aside_buf.slab));
+  o.aside_buf = ShadowBuf{};
+  if (o.d_counts) HIP_TRY(hipFree(o.d_counts));
+  if (o.d_stats) HIP_TRY(hipFree(o.d_stats));
+  o.d_counts = nullptr;
+  o.d_stats = nullptr;
+  o.depth = -1;
+  return RT_OK;
+}
+
 int rt::ensure_depth(rt_scene* s, int depth) {
   if (depth <= s->depth && !s->gens.empty()) return RT_OK;
+  {
+    int rc = release_other_lane(s);  // sized for the old depth; made again when frames are enqueued
+    if (rc) return rc;
+  }
   HIP_TRY(hipStreamSynchronize(main_stream(s)));
   if (s->d_counts) HIP_TRY(hipFree(s->d_counts));
   s->d_counts = nullptr;
@@ -368,6 +389,26 @@ static void hold_off(rt_scene* s) {
 
 static int run_pipeline_impl(rt_scene* s, const PipelineIn& in, rt_stats* stats, bool exact);
 
+// Makes the set that waits the set in use.  Frames enqueued before keep running on the set they were given.
+static int swap_lane(rt_scene* s) {
+  rt_scene::Lane& o = s->other_lane;
+  if (!o.stream) HIP_TRY(hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking));
+  if (o.depth != s->depth) {
+    int rc = release_other_lane(s);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc((void**)&o.d_counts, 2 * count_words(s->depth) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&o.d_stats, STAT_WORDS * sizeof(unsigned long long)));
+    o.gens.resize((size_t)s->depth + 2);
+    o.depth = s->depth;
+  }
+  std::swap(s->stream, o.stream);
+  std::swap(s->gens, o.gens);
+  std::swap(s->aside_buf, o.aside_buf);
+  std::swap(s->d_counts, o.d_counts);
+  std::swap(s->d_stats, o.d_stats);
+  return RT_OK;
+}
+
 int enqueue_speculative_frame(rt_scene* s, const PipelineIn& in, uint64_t primary, bool* enqueued) {
   *enqueued = false;
   const int max_gen = std::max(in.remaining0, 0);
@@ -392,6 +433,11 @@ int enqueue_speculative_frame(rt_scene* s, const PipelineIn& in, uint64_t primar
     f.h_counts = nullptr;
     HIP_TRY(hipHostMalloc((void**)&f.h_counts, count_words(s->depth) * sizeof(uint32_t), hipHostMallocDefault));
     f.counts_depth = s->depth;
+  }
+  static const bool one_lane = getenv("RT_AMD_ONE_LANE") != nullptr;
+  if (!one_lane) {  // the frame before this one keeps its set; this one takes the other
+    int rcl = swap_lane(s);
+    if (rcl) return rcl;
   }
   GenPlan plan(s->depth);
   int rc = launch_speculative(s, in, max_gen, plan, f.begin, f.end, f.h_counts, f.h_stats);

@@ -175,6 +175,18 @@ struct rt_scene {
   static constexpr int SPEC_SLOTS = 4;
   SpecFrame spec[SPEC_SLOTS];
   int spec_first = 0, spec_count = 0;
+  // Such frames alternate between two sets of what a frame in flight owns on the device -- ray records, queue
+  // counters, statistics, the stream -- so that the small late generations of one frame (a wave's life each, the
+  // GPU far from full) run beside the first generation of the next.  The set not in use waits here; the fields
+  // above (stream, gens, aside_buf, d_counts, d_stats) are the set in use (rt::swap_lane).  Made on first use.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    std::vector<rt::GenBuf> gens;
+    rt::ShadowBuf aside_buf;
+    uint32_t* d_counts = nullptr;
+    unsigned long long* d_stats = nullptr;
+    int depth = -1;  // recursion depth d_counts and gens were sized for
+  } other_lane;
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;
