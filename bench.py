@@ -164,6 +164,13 @@ def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
     }
 
 
+def metric_name(args):
+    """BASELINE.json's metric; another scene or size (a development run) is named as what it is."""
+    if os.path.basename(args.scene) == "teapot.json" and (args.width, args.height) == (1920, 1080):
+        return "rays/sec (node) on scenes/teapot.json at 1080p"
+    return "rays/sec (node) on %s at %dx%d (not the headline configuration)" % (os.path.relpath(args.scene, ROOT), args.width, args.height)
+
+
 def bench_single_process(args, timed=None):
     """One process drives all N GPUs (one native worker thread per GPU); every frame is complete in one page-locked
     host frame when the clock stops.  timed: under a launcher, the bracket every rank takes part in (barrier and
@@ -277,7 +284,7 @@ def bench_single_process(args, timed=None):
                                       info["triangles"], cores, s, s, W, H, cpu_rays, cpu_s, 4 * s, sum(res1["counts"]), cpu1_s)}
 
     out = {
-        "metric": "rays/sec (node) on scenes/teapot.json at 1080p",
+        "metric": metric_name(args),
         "value": rays_per_frame * args.steps / host_s,
         "unit": "rays/s",
         "n_gpus": n,
@@ -492,7 +499,7 @@ def bench_ranks(args, world):
     roofline["frac_per_frame_period"] = flops_frame / (host_s / args.steps) / (FP64_VALU_PEAK * world)
     if rank == 0:
         print(json.dumps({
-            "metric": "rays/sec (node) on scenes/teapot.json at 1080p" + (
+            "metric": metric_name(args) + (
                 "" if assembled_by_dma else ", every rank's part in host memory of its own (frame not assembled)"),
             "value": rays_per_frame * args.steps / host_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": host_s / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -640,7 +647,7 @@ def bench_ranks_rccl_gather(args, world):
     roofline["scope"] = "rank 0's part of the frame"
     if rank == 0:
         print(json.dumps({
-            "metric": "rays/sec (node) on scenes/teapot.json at 1080p",
+            "metric": metric_name(args),
             "value": rays_per_frame * args.steps / host_elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": host_elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
