@@ -96,6 +96,27 @@ def test_finer_bands_assemble_the_same_frame(pkg, root, rows):
     assert np.array_equal(got, one.render()[0]["rgb8"])
 
 
+@pytest.mark.parametrize("name", ["teapot", "glass"])
+def test_eight_frames_in_flight(pkg, root, name):
+    """The ring depth bench.py uses when a frame is cut into four parts or more: eight device frames, eight host frames
+    and eight copy fences per part.  The glass scene's frames are several generations of rays each: they are enqueued
+    unverified on two sets of ray records in turn and copied one frame late."""
+    path = os.path.join(root, "scenes", name + ".json")
+    one = pkg.Scene.from_file(path, base_dir=root, device=0)
+    one.set_canvas(240, 136)
+    want = one.render(rgb64=False, hit_leaf=False)[0]["rgb8"]
+    host = pkg.Scene.from_file(path, base_dir=root, device=None)
+    host.set_canvas(240, 136)
+    loop = host.frame_loop([0, 0, 0, 0], depth=8)
+    seconds, stats = loop.run(3, 21, True)  # 24 frames: every slot written three times
+    assert sum(s.primary for s in stats) == 21 * 240 * 136
+    for slot in range(8):
+        assert np.array_equal(loop.host_frame(slot), want), slot
+    seconds, stats = loop.run(0, 5, False)  # left in HBM: collected by the wait at the end of the stretch
+    assert sum(s.primary for s in stats) == 5 * 240 * 136
+    loop.close()
+
+
 def test_clone_renders_the_same_frame(pkg, root):
     import ctypes as C
     amd, _ = pkg.bindings.libraries()
