@@ -2,7 +2,7 @@
 """Headline benchmark: rays/sec and ms/frame on scenes/teapot.json at 1920x1080.
 
 One step = one frame, timed from ray generation to the framebuffer on the host: every GPU renders
-its bands of 32 pixel rows of the image (scene replicated per GPU, built once and cloned) and copies
+its bands of 8 pixel rows of the image (scene replicated per GPU, built once and cloned) and copies
 exactly those bands over its own PCIe link into one page-locked host frame; there is no GPU-to-GPU
 exchange.  `python bench.py --gpus N` is one process that drives N GPUs with one native worker thread
 per GPU (the host library's FrameLoop, the many-frame form of parallel_render, src/parallel.rs:183-204).
@@ -302,8 +302,8 @@ def bench_single_process(args, timed=None):
             "rays_per_frame": rays_per_frame,
             "timed_region": "frames left in HBM (--hbm-only: a profiling run, not the metric's region)" if args.hbm_only
                             else "ray generation to the finished frame in page-locked host memory",
-            "parallelism": "one process, %d part(s) = bands of 32 pixel rows dealt round-robin, one worker thread, one scene copy "
-                           "and one PCIe link per GPU, all parts copied into one shared host frame; no collective" % n + (
+            "parallelism": "one process, %d part(s) = bands of %d pixel rows dealt round-robin, one worker thread, one scene copy "
+                           "and one PCIe link per GPU, all parts copied into one shared host frame; no collective" % (n, loop.band_rows) + (
                                "" if timed is None else "; started by a launcher with one rank per GPU: rank 0 drives the GPUs, the "
                                "other ranks hold their GPU and take part in the barriers and the MAX over the ranks' times"),
             "frame_assembled_in_timed_region": True,
@@ -387,7 +387,7 @@ def bench_launched(args, world):
 
 def bench_ranks(args, world):
     """One rank per GPU under torch.distributed, no data-path collective: every rank runs the host library's
-    FrameLoop for its own part of the frame (bands of 32 pixel rows, part = rank) and copies exactly those
+    FrameLoop for its own part of the frame (bands of 8 pixel rows, part = rank) and copies exactly those
     bands over its own GPU's PCIe link into one ring of frames in shared memory that every rank has mapped
     and page-locked.  torch.distributed carries only the barriers around the timed region, the MAX over the
     ranks' times and the sums of the ray counts."""
@@ -515,9 +515,9 @@ def bench_ranks(args, world):
                     "machines this was built on refuse)"),
                 "frame_assembled_by_dma_in_shared_memory": assembled_by_dma,
                 "frame_assembled_in_timed_region": bool(assembled_by_dma),
-                "parallelism": "one rank per GPU, %d parts = bands of 32 pixel rows dealt round-robin, scene replicated, each "
+                "parallelism": "one rank per GPU, %d parts = bands of %d pixel rows dealt round-robin, scene replicated, each "
                                "rank copies its bands over its own PCIe link into the shared frame; no collective on the "
-                               "data path" % world,
+                               "data path" % (world, loop.band_rows),
                 "rehearsal": backend != "nccl"},
             "roofline": roofline, "cpu_baseline": None,
             "frames_left_in_hbm": None if hbm_s is None else {

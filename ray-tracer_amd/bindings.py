@@ -357,8 +357,8 @@ class HostFrameRing:
 
 class FrameLoop:
     """The host library's render loop over several GPUs of this process (host/rt_host.hpp FrameLoop):
-    one worker thread and one copy of the scene per part, each GPU copying its own bands of 32 pixel
-    rows into a ring of page-locked host frames shared by all parts.
+    one worker thread and one copy of the scene per part, each GPU copying its own bands of pixel rows
+    (band_rows: 8 unless RT_AMD_BAND_ROWS says 16 or 32) into a ring of page-locked host frames shared by all parts.
 
     With `ring` (a SharedFrameRing or HostFrameRing) the loop renders only parts first_part .. first_part + len(devices) - 1
     of total_parts and assembles the frames in the ring: one process per GPU, no collective."""

@@ -134,7 +134,7 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
 
 // parallel_render's workers kept alive over many frames (the reference renders one frame per process,
 // src/main.rs:71; a viewer or a camera sweep renders many).  One worker thread and one copy of the scene
-// per part; part k renders the bands of 32 pixel rows k, k + parts, ... on device devices[k] and copies
+// per part; part k renders the bands of 8 pixel rows (RT_AMD_BAND_ROWS: 16, 32) k, k + parts, ... on device devices[k] and copies
 // exactly those bands over that GPU's own link into a host frame all workers share, so a frame is
 // complete when every worker has passed it and no GPU-to-GPU exchange takes place.  The acceleration
 // structure is built once (rt_scene_create on the first device, rt_scene_clone for the others).

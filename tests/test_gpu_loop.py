@@ -1,5 +1,6 @@
 """The many-frame form of parallel_render (src/parallel.rs:183-204): one worker and one scene copy per
-part, every part copying its own bands of 32 pixel rows into one shared host frame.  On the one GPU of
+part, every part copying its own bands of pixel rows (8 rows high in the loop; 16 or 32 on request) into one shared
+host frame.  On the one GPU of
 the test box all parts run on device 0; the frame must equal the frame one part renders, byte for byte."""
 import json
 import os
