@@ -1,4 +1,4 @@
-"""The acceleration structure built on the GPU (bvh_device.hip: Morton order, binary radix tree, collapse
+"""The acceleration structure built on the GPU (bvh_device.hip: binned surface-area splits top down, collapse
 to the 4-wide layout) against the CPU oracle (the reference's algorithm: every child of every group scanned,
 src/shape.rs:1213-1219) and against the hierarchy the host builds (binned SAH): all are conservative over the
 same shapes, so every image, hit leaf and ray count must be the same."""
@@ -117,6 +117,29 @@ def test_crowd_with_groups_built_on_the_device(pkg, tmp_path):
     equals_oracle(r_dev, json.dumps(scene))
     same(r_host, r_dev)
     assert f_dev["device_builds"] >= 9
+
+
+def test_shapes_the_splits_cannot_separate(pkg):
+    """Where no bin boundary separates a node's items -- many shapes at one place, shapes strung along one line --
+    the device builder halves the stretch instead; and two items are the smallest tree there is."""
+    def ball(x, y, z, r):
+        return {"ty": "sphere", "transform": [r, 0, 0, x, 0, r, 0, y, 0, 0, r, z, 0, 0, 0, 1],
+                "material": {"color": [0.3 + 0.1 * (int(x * 7) % 5), 0.5, 0.7]}}
+
+    base = json.load(open(os.path.join(ROOT, "scenes", "example.json")))
+    base.update(canvas_width=96, canvas_height=54, camera_from=[0.0, 3.0, -14.0], camera_to=[0.0, 0.5, 0.0])
+    crowds = {
+        "300 spheres at one place, 5 elsewhere": [ball(0.0, 1.0, 0.0, 1.0)] * 300 + [ball(-4.0 + 2.0 * k, 0.0, 2.0, 0.6) for k in range(5)],
+        "400 spheres along a line, touching": [ball(-6.0 + 0.03 * k, 0.0, 0.0, 0.5) for k in range(400)],
+        "two spheres": [ball(-1.0, 0.0, 0.0, 1.0), ball(1.5, 0.5, 1.0, 1.0)],
+        "three spheres": [ball(-2.0, 0.0, 0.0, 1.0), ball(0.5, 0.5, 1.0, 1.0), ball(3.0, 0.0, 0.0, 1.0)],
+    }
+    for what, shapes in crowds.items():
+        text = json.dumps(dict(base, shapes=shapes))
+        (host, r_host, f_host), (dev, r_dev, f_dev) = both(pkg, text)
+        assert f_dev["device_builds"] >= 1 and f_host["device_builds"] == 0, what
+        same(r_host, r_dev)
+        equals_oracle(r_dev, text)
 
 
 def test_a_million_triangles_build_in_milliseconds(pkg, tmp_path):
