@@ -45,7 +45,7 @@ def test_teapot_1080p(pkg):
     assert np.array_equal(acc, out["rgb64"]) and shadow == st.shadow
     ref = orc.OracleScene.from_file(path, base_dir=ROOT)
     ref.set_canvas(1920, 1080)
-    subsample_check(out, ref, 24, x0=5, y0=7)  # 80 x 45 pixels of the same frame through the oracle
+    subsample_check(out, ref, 2, x0=1, y0=1)  # 960 x 540 pixels of the same frame through the oracle (bench.py checks all of them)
 
 
 def test_glass_4k_properties(pkg):
@@ -57,7 +57,7 @@ def test_glass_4k_properties(pkg):
     assert st.shadow == st.primary - int((out["hit_leaf"] < 0).sum()) + (st.shadow - int((out["hit_leaf"] >= 0).sum()))
     assert np.array_equal(out["rgb8"], orc.quantise(out["rgb64"]))
     ref = orc.OracleScene.from_file(path, base_dir=ROOT)
-    subsample_check(out, ref, 48, x0=11, y0=3)
+    subsample_check(out, ref, 1)  # every pixel of the 4K frame
 
 
 @pytest.fixture(scope="module")
@@ -108,7 +108,7 @@ def test_heightfield_mesh_full_size(pkg, gen_dir):
     again, _ = s.render(rgb8=False, hit_leaf=False)
     assert np.array_equal(again["rgb64"], out["rgb64"])
     ref = orc.OracleScene.from_file(path, base_dir=ROOT)
-    subsample_check(out, ref, 240, x0=100, y0=60)  # 16 x 9 pixels: each costs two scans of a million triangles
+    subsample_check(out, ref, 120, x0=100, y0=60)  # 32 x 18 pixels: each costs two scans of a million triangles
 
 
 def test_primitive_field_full_size(pkg, gen_dir):
@@ -120,7 +120,7 @@ def test_primitive_field_full_size(pkg, gen_dir):
     assert st.primary == 7680 * 4320
     assert st.shadow >= int((out["hit_leaf"] >= 0).sum())
     assert st.refract == 0 and st.reflect > 0
-    rays = s.ray_for_pixel(np.array([[x, y] for y in range(100, 4320, 480) for x in range(100, 7680, 640)], np.uint32))
+    rays = s.ray_for_pixel(np.array([[x, y] for y in range(100, 4320, 240) for x in range(100, 7680, 320)], np.uint32))  # 432 pixels
     ref = orc.OracleScene.from_file(path, base_dir=ROOT)
     rgb, leaf, _ = s.color_at(rays)
     want, wleaf, _ = ref.color_at(rays)
