@@ -9,9 +9,8 @@
 
 using namespace rt;
 
-// Releases what the lane not in use holds on the device (its stream stays).
-static int release_other_lane(rt_scene* s) {
-  rt_scene::Lane& o = s->other_lane;
+// Releases what a set that is not in use holds on the device (its stream stays).
+static int release_lane(rt_scene::Lane& o) {
   if (o.stream) HIP_TRY(hipStreamSynchronize(o.stream));
   for (GenBuf& g : o.gens)
     if (g.slab) HIP_TRY(hipFree(g.slab));
@@ -29,8 +28,10 @@ static int release_other_lane(rt_scene* s) {
 int rt::ensure_depth(rt_scene* s, int depth) {
   if (depth <= s->depth && !s->gens.empty()) return RT_OK;
   {
-    int rc = release_other_lane(s);  // sized for the old depth; made again when frames are enqueued
-    if (rc) return rc;
+    for (rt_scene::Lane& o : s->spare_lane) {  // sized for the old depth; made again when frames are enqueued
+      int rc = release_lane(o);
+      if (rc) return rc;
+    }
   }
   HIP_TRY(hipStreamSynchronize(main_stream(s)));
   if (s->d_counts) HIP_TRY(hipFree(s->d_counts));
@@ -390,11 +391,12 @@ static void hold_off(rt_scene* s) {
 static int run_pipeline_impl(rt_scene* s, const PipelineIn& in, rt_stats* stats, bool exact);
 
 // Makes the set that waits the set in use.  Frames enqueued before keep running on the set they were given.
-static int swap_lane(rt_scene* s) {
-  rt_scene::Lane& o = s->other_lane;
+static int swap_lane(rt_scene* s, int spares) {
+  rt_scene::Lane& o = s->spare_lane[s->next_spare % spares];
+  s->next_spare = (s->next_spare + 1) % spares;
   if (!o.stream) HIP_TRY(hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking));
   if (o.depth != s->depth) {
-    int rc = release_other_lane(s);
+    int rc = release_lane(o);
     if (rc) return rc;
     HIP_TRY(hipMalloc((void**)&o.d_counts, 2 * count_words(s->depth) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&o.d_stats, STAT_WORDS * sizeof(unsigned long long)));
@@ -434,9 +436,11 @@ int enqueue_speculative_frame(rt_scene* s, const PipelineIn& in, uint64_t primar
     HIP_TRY(hipHostMalloc((void**)&f.h_counts, count_words(s->depth) * sizeof(uint32_t), hipHostMallocDefault));
     f.counts_depth = s->depth;
   }
-  static const bool one_lane = getenv("RT_AMD_ONE_LANE") != nullptr;
-  if (!one_lane) {  // the frame before this one keeps its set; this one takes the other
-    int rcl = swap_lane(s);
+  // sets of ray records the enqueued frames take in turn (RT_AMD_LANES=1: all frames on one set and one stream)
+  static const int lanes = getenv("RT_AMD_LANES") ? std::min(std::max(atoi(getenv("RT_AMD_LANES")), 1), rt_scene::MAX_SPARE_LANES + 1)
+                                                  : (getenv("RT_AMD_ONE_LANE") ? 1 : 2);
+  if (lanes > 1) {  // the frames before this one keep their sets; this one takes the set that has waited longest
+    int rcl = swap_lane(s, lanes - 1);
     if (rcl) return rcl;
   }
   GenPlan plan(s->depth);

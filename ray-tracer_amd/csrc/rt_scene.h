@@ -186,7 +186,10 @@ struct rt_scene {
     uint32_t* d_counts = nullptr;
     unsigned long long* d_stats = nullptr;
     int depth = -1;  // recursion depth d_counts and gens were sized for
-  } other_lane;
+  };
+  static constexpr int MAX_SPARE_LANES = 3;
+  Lane spare_lane[MAX_SPARE_LANES];
+  int next_spare = 0;  // the spare set the next enqueued frame takes
   // staging for the host-buffer entry points
   void* stage = nullptr;
   size_t stage_bytes = 0;

@@ -525,7 +525,8 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   (void)hipSetDevice(s->device);
   // frames may still run on any render stream and copies on the copy stream: drain them all
   // before any of the memory they use is released
-  for (hipStream_t st : {s->stream, s->other_lane.stream, s->frame_stream[0], s->frame_stream[1], s->frame_stream[2], s->copy_stream})
+  for (hipStream_t st : {s->stream, s->spare_lane[0].stream, s->spare_lane[1].stream, s->spare_lane[2].stream, s->frame_stream[0],
+                         s->frame_stream[1], s->frame_stream[2], s->copy_stream})
     if (st) (void)hipStreamSynchronize(st);
   for (const rt_scene::Alloc& a : s->allocs) (void)hipFree(a.p);
   for (GenBuf& g : s->gens)
@@ -548,8 +549,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   for (rt_scene::FrameSlot& f : s->slots)
     for (hipEvent_t e : {f.begin, f.end})
       if (e) (void)hipEventDestroy(e);
-  {
-    rt_scene::Lane& o = s->other_lane;
+  for (rt_scene::Lane& o : s->spare_lane) {
     if (o.stream) (void)hipStreamSynchronize(o.stream);
     for (GenBuf& g : o.gens)
       if (g.slab) (void)hipFree(g.slab);
@@ -1281,7 +1281,8 @@ static int scene_rebuild(rt_scene* s, const rt_scene_desc* d) {
   if (rc != RT_OK) return rc;
   rc = collect_all(s);
   if (rc == RT_OK)
-    for (hipStream_t st : {s->stream, s->other_lane.stream, s->frame_stream[0], s->frame_stream[1], s->frame_stream[2], s->copy_stream})
+    for (hipStream_t st : {s->stream, s->spare_lane[0].stream, s->spare_lane[1].stream, s->spare_lane[2].stream, s->frame_stream[0],
+                           s->frame_stream[1], s->frame_stream[2], s->copy_stream})
       if (st && hipStreamSynchronize(st) != hipSuccess) rc = fail(RT_ERR_DEVICE, "rt_scene_update: a stream of the scene failed");
   if (rc != RT_OK) {
     std::string keep = last_error_text();
