@@ -282,7 +282,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, u
  * ninth call waits for the oldest.  A scene whose materials spawn reflection or refraction rays is a
  * row of ray generations: its first frame for a camera size and depth is rendered one generation at a
  * time (the call blocks, its counts still go to rt_scene_wait); later frames launch every generation at
- * once on the queue lengths of the last frame and are only enqueued, up to four in flight.  Whether such
+ * once on the queue lengths of the last frame and are only enqueued, up to three in flight.  Whether such
  * a frame's queues had room is known when its counters are back, and the library looks at them before
  * anything reads the frame: in rt_download / rt_download_2d of its image (which therefore wait for that
  * frame, not for the frames enqueued after it), in rt_scene_wait and in every blocking entry point.  A

@@ -389,6 +389,7 @@ static void hold_off(rt_scene* s) {
 }
 
 static int run_pipeline_impl(rt_scene* s, const PipelineIn& in, rt_stats* stats, bool exact);
+static int verify_oldest(rt_scene* s, int upto);
 
 // Makes the set that waits the set in use.  Frames enqueued before keep running on the set they were given.
 static int swap_lane(rt_scene* s, int spares) {
@@ -417,11 +418,16 @@ int enqueue_speculative_frame(rt_scene* s, const PipelineIn& in, uint64_t primar
   static const bool off = getenv("RT_AMD_NO_ASYNC_GENERATIONS") != nullptr;
   if (off || speculation_off() || s->max_children == 0 || max_gen == 0 || (in.flags & RT_FLAG_COUNTERS) || !in.camera) return RT_OK;
   if (std::max(max_gen, RECURSION_DEPTH) > s->depth || !hints_match(s, in) || s->holdoff > 0) return RT_OK;
-  if (s->spec_count == rt_scene::SPEC_SLOTS) {  // the oldest makes room; it may turn out not to have fitted
-    int rc = verify_frames(s, s->spec[s->spec_first].in.img.rgb8 ? (const void*)s->spec[s->spec_first].in.img.rgb8
-                                                                    : (const void*)&s->spec[s->spec_first], nullptr);
+  // Unverified frames in flight, this one included (RT_AMD_FRAMES_IN_FLIGHT: 1..4).  Two sets of ray records want
+  // two; a third keeps a set's stream fed while the host looks at the frame before, a fourth measured slower on the
+  // 100k-primitive sweep (10.2-10.4 ms per frame against 10.0 with two or three; glass 4K the same either way).
+  static const int in_flight = getenv("RT_AMD_FRAMES_IN_FLIGHT")
+                                   ? std::min(std::max(atoi(getenv("RT_AMD_FRAMES_IN_FLIGHT")), 1), (int)rt_scene::SPEC_SLOTS)
+                                   : 3;
+  if (s->spec_count >= in_flight) {  // the oldest make room; they may turn out not to have fitted
+    int rc = verify_oldest(s, s->spec_count - in_flight + 1);
     if (rc) return rc;
-    if (s->spec_count == rt_scene::SPEC_SLOTS || !hints_match(s, in) || s->holdoff > 0) return RT_OK;
+    if (s->spec_count >= in_flight || !hints_match(s, in) || s->holdoff > 0) return RT_OK;
   }
   rt_scene::SpecFrame& f = s->spec[(s->spec_first + s->spec_count) % rt_scene::SPEC_SLOTS];
   if (!f.begin) {
@@ -463,19 +469,12 @@ static bool frame_holds(const rt_scene::SpecFrame& f, const void* p) {
     return base && (const char*)p >= (const char*)base && (const char*)p < (const char*)base + bytes;
   };
   return within(f.in.img.rgb8, pixels * 3) || within(f.in.img.rgb64, pixels * 3 * sizeof(double)) ||
-         within(f.in.img.hit_leaf, pixels * sizeof(int32_t)) || p == (const void*)&f;
+         within(f.in.img.hit_leaf, pixels * sizeof(int32_t));
 }
 
-int verify_frames(rt_scene* s, const void* touching, bool* was_frame) {
-  if (was_frame) *was_frame = false;
-  int upto = s->spec_count;
-  if (touching) {
-    upto = 0;
-    for (int k = 0; k < s->spec_count; k++)
-      if (frame_holds(s->spec[(s->spec_first + k) % rt_scene::SPEC_SLOTS], touching)) upto = k + 1;
-    if (upto > 0 && was_frame) *was_frame = true;
-  }
-  for (int k = 0; k < upto; k++) {
+// Verifies the `upto` oldest unverified frames.
+static int verify_oldest(rt_scene* s, int upto) {
+  for (int k = 0; k < upto && s->spec_count > 0; k++) {
     rt_scene::SpecFrame& f = s->spec[s->spec_first];
     s->spec_first = (s->spec_first + 1) % rt_scene::SPEC_SLOTS;
     s->spec_count--;
@@ -498,8 +497,18 @@ int verify_frames(rt_scene* s, const void* touching, bool* was_frame) {
   return RT_OK;
 }
 
-// Runs the generations, resolves colours back into generation 0 and, for camera
-// rays, writes the image.  Fills the device-side fields of stats.
+int verify_frames(rt_scene* s, const void* touching, bool* was_frame) {
+  if (was_frame) *was_frame = false;
+  int upto = s->spec_count;
+  if (touching) {
+    upto = 0;
+    for (int k = 0; k < s->spec_count; k++)
+      if (frame_holds(s->spec[(s->spec_first + k) % rt_scene::SPEC_SLOTS], touching)) upto = k + 1;
+    if (upto > 0 && was_frame) *was_frame = true;
+  }
+  return verify_oldest(s, upto);
+}
+
 int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats) { return run_pipeline_impl(s, in, stats, false); }
 
 static int run_pipeline_impl(rt_scene* s, const PipelineIn& in, rt_stats* stats, bool exact) {
