@@ -443,8 +443,7 @@ int enqueue_speculative_frame(rt_scene* s, const PipelineIn& in, uint64_t primar
     f.counts_depth = s->depth;
   }
   // sets of ray records the enqueued frames take in turn (RT_AMD_LANES=1: all frames on one set and one stream)
-  static const int lanes = getenv("RT_AMD_LANES") ? std::min(std::max(atoi(getenv("RT_AMD_LANES")), 1), rt_scene::MAX_SPARE_LANES + 1)
-                                                  : (getenv("RT_AMD_ONE_LANE") ? 1 : 2);
+  static const int lanes = getenv("RT_AMD_LANES") ? std::min(std::max(atoi(getenv("RT_AMD_LANES")), 1), rt_scene::MAX_SPARE_LANES + 1) : 2;
   if (lanes > 1) {  // the frames before this one keep their sets; this one takes the set that has waited longest
     int rcl = swap_lane(s, lanes - 1);
     if (rcl) return rcl;
