@@ -46,14 +46,15 @@ DEPTH = int(os.environ.get("RT_BENCH_DEPTH", "4"))  # frames in flight per GPU =
 
 
 def ring_depth(parts):
-    """Frames in flight per GPU.  A quarter or an eighth of the frame is one round of waves, so its launch lasts as
-    long as its slowest wave whatever else the GPU could do: only more launches in flight fill it (tools/part_period.py,
-    one GPU rendering its part of N: 0.0534 -> 0.0449 ms per frame at N = 4 and 0.0433 -> 0.0340 at N = 8 with eight
-    instead of four).  Whole and half frames are bound by their copies, and eight host frames of 6.2 MB fall out of the
-    host's last-level cache (0.124 -> 0.160 ms per frame at N = 1)."""
+    """Frames in flight per GPU.  A part of the frame is a short launch that lasts as long as its slowest wave whatever
+    else the GPU could do, and a copy costs about 8 us whatever it moves: the loop therefore renders four frames of a
+    part with one launch and moves them with one copy, and keeps four such launches in flight (tools/part_period.py,
+    one GPU rendering its part of N, ms per frame on the host: N = 2 0.070 -> 0.061, N = 4 0.043 -> 0.033, N = 8
+    0.034 -> 0.019 against one frame per launch in a ring of eight).  Whole frames are bound by their copy, and eight
+    host frames of 6.2 MB fall out of the host's last-level cache (0.124 -> 0.160 ms per frame at N = 1)."""
     if "RT_BENCH_DEPTH" in os.environ:
         return DEPTH
-    return 8 if parts >= 4 else 4
+    return 16 if parts >= 2 else 4
 # Untimed frames before the warmup, as a stretch of their own that ends with every GPU idle.  A fresh process pays
 # about 20 ms once: code objects and runtime pools with the first launches, and about 5.6 ms for each of three DMA
 # engines on that engine's first copy -- the runtime turns to a second and third engine only when a copy finds the
@@ -323,7 +324,8 @@ def bench_single_process(args, timed=None):
         "PCIe_GBps": W * H * 3 * args.steps / host_s / 1e9,
         "breakdown_ms": {"frame": host_s / args.steps * 1e3, "generation_kernels_per_frame": piped["kernel_ms"] / args.steps,
                          "lone_frame_kernel": lone["kernel_ms"] / 10},
-        "pipeline": {"frames_in_flight_per_gpu": depth, "untimed_priming_frames": PRIMING},
+        "pipeline": {"frames_in_flight_per_gpu": depth, "frames_of_a_part_per_launch_and_copy": loop.frames_per_launch,
+                     "untimed_priming_frames": PRIMING},
         "frame_sha256": sha,
         "setup": {"scene_load_and_bvh_s": load_s, "bvh_build_s": linfo["build_seconds"], "scene_bytes": linfo["scene_bytes"],
                   "bvh_builds": 1},

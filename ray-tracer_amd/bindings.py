@@ -92,6 +92,7 @@ def libraries():
     amd.rt_scene_build_info.argtypes = [vp, C.POINTER(u64), dp]
     amd.rt_render.argtypes = [vp, C.POINTER(RtCamera), i32, i32, u32, vp, vp, vp, C.POINTER(RtStats)]
     amd.rt_scene_wait.argtypes = [vp, C.POINTER(RtStats)]
+    amd.rt_render_frames.argtypes = [vp, C.POINTER(RtCamera), i32, i32, i32, u32, C.POINTER(vp)]
     amd.rt_scene_stream.argtypes = [vp, C.POINTER(vp)]
     amd.rt_scene_copy_stream.argtypes = [vp, C.POINTER(vp)]
     amd.rt_download.argtypes = [vp, vp, vp, u64, vp]
@@ -421,10 +422,18 @@ class FrameLoop:
 
     @property
     def band_rows(self):
-        """Rows of a band of this loop's parts (32, or what RT_AMD_BAND_ROWS asked for when the loop was made)."""
+        """Rows of a band of this loop's parts (8, or what RT_AMD_BAND_ROWS asked for when the loop was made)."""
         self._host.rth_frame_loop_band_rows.restype = C.c_uint64
         self._host.rth_frame_loop_band_rows.argtypes = [C.c_void_p]
         return int(self._host.rth_frame_loop_band_rows(self._l))
+
+    @property
+    def frames_per_launch(self):
+        """Frames of a part the last run() put into one kernel launch (rt_render_frames): 1 for a whole frame and for
+        scenes that spawn rays, 2 for halves, 4 from four parts on, at most half the ring; RT_AMD_FRAMES_PER_LAUNCH."""
+        self._host.rth_frame_loop_frames_per_launch.restype = C.c_uint64
+        self._host.rth_frame_loop_frames_per_launch.argtypes = [C.c_void_p]
+        return int(self._host.rth_frame_loop_frames_per_launch(self._l))
 
     def info(self):
         out = (C.c_uint64 * 2)()
@@ -566,6 +575,16 @@ class Scene:
                                         C.c_void_p(rgb8_ptr or None), C.c_void_p(rgb64_ptr or None),
                                         C.c_void_p(hit_leaf_ptr or None), C.byref(st)))
         return st
+
+    def render_frames_device(self, cameras, rgb8_ptrs, part=0, n_parts=1, bands=False, band_rows=32):
+        """rt_render_frames: frame k through cameras[k] (RtCamera structs, e.g. copies of camera() taken between
+        set_camera calls) into the device buffer at rgb8_ptrs[k]; enqueued, collect with wait()."""
+        n = len(cameras)
+        cams = (RtCamera * n)(*cameras)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(p) for p in rgb8_ptrs])
+        flags = (RT_FLAG_ASYNC | (RT_FLAG_BANDS if bands else 0)
+                 | ({32: 0, 16: RT_FLAG_BANDS_16, 8: RT_FLAG_BANDS_8}[band_rows] if bands else 0))
+        self._check(self._amd.rt_render_frames(self._dev(), cams, n, part, n_parts, flags, ptrs))
 
     def wait(self):
         """rt_scene_wait: blocks until the enqueued frames are complete; sums of their statistics."""

@@ -138,16 +138,15 @@ extern "C" int rt_scene_footprint(const rt_scene* s, uint64_t* scene_bytes, doub
 // rows of a band under RT_FLAG_BANDS: 32, or 16 / 8 when the caller asks for finer bands
 static uint32_t band_rows(uint32_t flags) { return (flags & RT_FLAG_BANDS_8) ? 8u : ((flags & RT_FLAG_BANDS_16) ? 16u : 32u); }
 
-extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_parts, uint32_t flags,
-                         uint8_t* rgb8_dev, double* rgb64_dev, int32_t* hit_leaf_dev, rt_stats* stats) {
-  if (!s || !camera) return fail(RT_ERR_INVALID, "null argument");
+// What rt_render and rt_render_frames share: the arguments checked, the part's tile table on the device, the
+// pipeline's input for this camera, and how many of the part's pixels lie inside the image.
+static int prepare_camera_frame(rt_scene* s, const rt_camera* camera, int part, int n_parts, uint32_t flags, uint8_t* rgb8_dev,
+                                double* rgb64_dev, int32_t* hit_leaf_dev, PipelineIn& in, uint64_t& valid) {
   if (n_parts < 1 || part < 0 || part >= n_parts) return fail(RT_ERR_INVALID, "part must lie in [0, n_parts)");
   if (camera->hsize == 0 || camera->vsize == 0) return fail(RT_ERR_INVALID, "empty canvas");
   if (!affine(camera->inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) camera transform");
-  auto w0 = std::chrono::steady_clock::now();
   RT_REQUIRE_USABLE(s);
   HIP_TRY(hipSetDevice(s->device));
-  if (stats) memset(stats, 0, sizeof(*stats));
   const bool bands = (flags & RT_FLAG_BANDS) != 0;
   const uint32_t tile_h = bands ? band_rows(flags) : (uint32_t)TILE;
   uint32_t tiles_x = (camera->hsize + TILE - 1) / TILE, tiles_y = (camera->vsize + tile_h - 1) / tile_h;
@@ -175,8 +174,6 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   }
   uint64_t n64 = (uint64_t)s->h_tiles.size() * TILE * tile_h;
   if (n64 > 0xFFFFFF00ull) return fail(RT_ERR_UNSUPPORTED, "canvas part exceeds 2^32 rays");
-  if (n64 == 0) return RT_OK;
-  PipelineIn in;
   in.n0 = (uint32_t)n64;
   in.flags = flags;
   in.camera = true;
@@ -188,12 +185,25 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
   if ((flags & RT_FLAG_COMPACT) && (rgb64_dev || hit_leaf_dev || !rgb8_dev))
     return fail(RT_ERR_INVALID, "the compact layout is for rgb8 only");
   in.img = ImageOut{rgb8_dev, rgb64_dev, hit_leaf_dev, (flags & RT_FLAG_COMPACT) ? 1u : 0u};
-  uint64_t valid = 0;
+  valid = 0;
   for (uint32_t t : s->h_tiles) {
     uint32_t x0 = (t % tiles_x) * TILE, y0 = (t / tiles_x) * tile_h;
     uint32_t w = std::min<uint32_t>(TILE, camera->hsize - x0), h = std::min<uint32_t>(tile_h, camera->vsize - y0);
     valid += (uint64_t)w * h;
   }
+  return RT_OK;
+}
+
+extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_parts, uint32_t flags,
+                         uint8_t* rgb8_dev, double* rgb64_dev, int32_t* hit_leaf_dev, rt_stats* stats) {
+  if (!s || !camera) return fail(RT_ERR_INVALID, "null argument");
+  auto w0 = std::chrono::steady_clock::now();
+  if (stats) memset(stats, 0, sizeof(*stats));
+  PipelineIn in;
+  uint64_t valid = 0;
+  int rc = prepare_camera_frame(s, camera, part, n_parts, flags, rgb8_dev, rgb64_dev, hit_leaf_dev, in, valid);
+  if (rc) return rc;
+  if (in.n0 == 0) return RT_OK;
   if ((flags & RT_FLAG_ASYNC) && s->max_children == 0) return enqueue_direct_frame(s, in, valid);
   if (flags & RT_FLAG_ASYNC) {  // a scene that spawns rays: every generation at once, verified later, when it can be
     bool enqueued = false;
@@ -204,7 +214,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
       return RT_OK;
     }
   }
-  int rc = collect_all(s);  // frames still in flight finish first
+  rc = collect_all(s);  // frames still in flight finish first
   if (rc) return rc;
   s->last_stream = s->stream;
   rt_stats local{};
@@ -221,6 +231,42 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* camera, int part, int n_p
     stats->render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   }
   return RT_OK;
+}
+
+extern "C" int rt_render_frames(rt_scene* s, const rt_camera* cameras, int n_frames, int part, int n_parts, uint32_t flags,
+                                uint8_t* const* rgb8_dev) {
+  if (!s || !cameras || !rgb8_dev) return fail(RT_ERR_INVALID, "null argument");
+  if (n_frames < 1 || n_frames > RT_MAX_FRAMES_PER_CALL) return fail(RT_ERR_INVALID, "n_frames must lie in 1..RT_MAX_FRAMES_PER_CALL");
+  if (!(flags & RT_FLAG_ASYNC)) return fail(RT_ERR_INVALID, "rt_render_frames enqueues its frames: pass RT_FLAG_ASYNC");
+  for (int k = 0; k < n_frames; k++) {
+    if (!rgb8_dev[k]) return fail(RT_ERR_INVALID, "null frame");
+    if (cameras[k].hsize != cameras[0].hsize || cameras[k].vsize != cameras[0].vsize)
+      return fail(RT_ERR_INVALID, "the frames of one call share one canvas size");
+    if (!affine(cameras[k].inv)) return fail(RT_ERR_UNSUPPORTED, "projective (non-affine) camera transform");
+  }
+  static_assert(RT_MAX_FRAMES_PER_CALL == MAX_LAUNCH_FRAMES, "the header's limit is the kernel's");
+  // One launch where a frame is one kernel: a scene that spawns no rays, whose CSG hit lists (if any) live in LDS.
+  // Every other scene gets its frames one after the other, as from rt_render.
+  const bool one_launch = n_frames > 1 && s->max_children == 0 && !s->dev.csg_spill;
+  if (!one_launch) {
+    for (int k = 0; k < n_frames; k++) {
+      int rc = rt_render(s, &cameras[k], part, n_parts, flags, rgb8_dev[k], nullptr, nullptr, nullptr);
+      if (rc) return rc;
+    }
+    return RT_OK;
+  }
+  PipelineIn in;
+  uint64_t valid = 0;
+  int rc = prepare_camera_frame(s, &cameras[0], part, n_parts, flags, rgb8_dev[0], nullptr, nullptr, in, valid);
+  if (rc) return rc;
+  if (in.n0 == 0) return RT_OK;
+  CameraDev more[MAX_LAUNCH_FRAMES - 1];
+  for (int k = 1; k < n_frames; k++) {
+    more[k - 1] = camera_dev(&cameras[k]);
+    more[k - 1].tile_h = in.cam.tile_h;
+    more[k - 1].tile_shift = in.cam.tile_shift;
+  }
+  return enqueue_direct_frames(s, in, valid, n_frames, more, rgb8_dev + 1);
 }
 
 extern "C" int rt_scene_wait(rt_scene* s, rt_stats* total) {

@@ -34,7 +34,8 @@ template <bool COUNT, int MODE, bool CSG, bool UNIFORM, bool TRIPF = false>
 __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : RT_MIN_WAVES_SPAWN)
     k_generation(SceneDev S, GenView g, uint32_t n, GenView next, uint32_t next_segcap, int remaining,
                  uint32_t* next_counts, unsigned long long* stats, CameraDev cam, const uint32_t* tiles,
-                 uint32_t tiles_x, ImageOut img, const uint32_t* queue_counts, uint32_t segcap, ShadowView aside) {
+                 uint32_t tiles_x, ImageOut img, const uint32_t* queue_counts, uint32_t segcap, ShadowView aside,
+                 FrameBatch batch) {
   // dynamic LDS: SceneDev::stack_entries * BLOCK words of traversal stack, then SceneDev::csg_hits * 3 * BLOCK words
   // of CSG hit list when the scene has operators
   extern __shared__ uint32_t dyn_lds[];
@@ -66,6 +67,11 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
       wave_index = ((k / XCD_RUN) * XCDS + xcd) * XCD_RUN + k % XCD_RUN;
     }
   }
+  uint32_t frame = 0;  // which frame of the launch this wave belongs to
+  if (MODE == 0 && batch.frames > 1) {
+    frame = wave_index / batch.waves_per_frame;
+    wave_index -= frame * batch.waves_per_frame;
+  }
   wave_index += S.first_block;  // a job launched in pieces (SceneDev::csg_spill_slots)
   const uint32_t i = wave_index * BLOCK + thread_in_block();
   uint32_t rec = i;
@@ -76,7 +82,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
   Ray ray{v3(0, 0, 0), v3(0, 0, 1)};
   if (MODE != 2) {
     active = active && ray_pixel(tiles, tiles_x, cam, i, px, py);
-    if (active) ray = camera_ray(cam, px, py);
+    if (active) ray = camera_ray(MODE == 0 && frame ? batch.cam[frame - 1] : cam, px, py);
   } else if (active) {
     ray = load_ray(g, rec);
   }
@@ -314,6 +320,7 @@ __global__ void __launch_bounds__(BLOCK, MODE == 0 || UNIFORM ? RT_MIN_WAVES : R
     out_b = b2 ? (b2 - 0.5) / 255.0 : 0.0;
   }
 #endif
+  if (MODE == 0 && frame) img.rgb8 = batch.rgb8[frame - 1];
   if (MODE != 2) write_pixel(img, cam.hsize, px, py, i, active, out_r, out_g, out_b, leaf);
   if (MODE != 0 && keep_record) {
     g.cr[rec] = out_r; g.cg[rec] = out_g; g.cb[rec] = out_b;
@@ -400,8 +407,9 @@ void launch_generation_variant(const SceneDev& scene, unsigned lds_bytes, int mo
       launch(piece, dim3(std::min(scene.csg_spill_slots, blocks - first)));
     }
   };
-#define RT_GEN_ARGS dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap, a.aside
-  in_pieces((a.n + BLOCK - 1) / BLOCK, [&](const SceneDev& dev, dim3 grid) {
+#define RT_GEN_ARGS dev, a.cur, a.n, a.next, a.next_segcap, a.remaining, a.next_counts, a.stats, a.cam, a.tiles, a.tiles_x, a.img, a.queue_counts, a.segcap, a.aside, a.batch
+  const uint32_t frames = mode == 0 && a.batch.frames > 1 ? a.batch.frames : 1u;  // a.n rays each
+  in_pieces((a.n + BLOCK - 1) / BLOCK * frames, [&](const SceneDev& dev, dim3 grid) {
     if constexpr (TRIPF) {  // only camera rays of scenes that spawn nothing fetch triangles ahead
       hipLaunchKernelGGL((k_generation<COUNT, 0, CSG, UNIFORM, true>), grid, block, lds_bytes, a.stream, RT_GEN_ARGS);
     } else {

@@ -157,7 +157,7 @@ static int collect_frame(rt_scene* s, rt_scene::FrameSlot& f) {
   t.primary += f.primary;
   t.kernel_ms += ms;
   t.kernel_launches += 1;
-  t.generations += 1;
+  t.generations += f.frames;
   return RT_OK;
 }
 
@@ -202,6 +202,13 @@ int collect_all(rt_scene* s) {
 // One camera frame of a scene that spawns no rays: a single kernel, nothing to read back, so the
 // frame is only enqueued.
 int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
+  return enqueue_direct_frames(s, in, primary, 1, nullptr, nullptr);
+}
+
+// The same for n_frames frames in one launch (1..MAX_LAUNCH_FRAMES): frame 0 is `in`, frame k > 0 is seen through
+// more_cams[k - 1] and written to more_rgb8[k - 1].
+int enqueue_direct_frames(rt_scene* s, const PipelineIn& in, uint64_t primary, int n_frames, const CameraDev* more_cams,
+                          uint8_t* const* more_rgb8) {
   rt_scene::FrameSlot& f = s->slots[s->next_slot];
   int rc = collect_frame(s, f);  // the slot's previous frame, FRAME_SLOTS frames ago
   if (rc) return rc;
@@ -226,13 +233,22 @@ int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary) {
   a.tiles_x = in.tiles_x;
   a.img = in.img;
   a.stats = s->d_async_stats;
+  if (n_frames > 1) {
+    a.batch.frames = (uint32_t)n_frames;
+    a.batch.waves_per_frame = (in.n0 + BLOCK - 1) / BLOCK;
+    for (int k = 1; k < n_frames; k++) {
+      a.batch.cam[k - 1] = more_cams[k - 1];
+      a.batch.rgb8[k - 1] = more_rgb8[k - 1];
+    }
+  }
   s->async_counters_dirty = true;
   a.stream = stream;
   HIP_TRY(hipEventRecord(f.begin, stream));
   launch_generation(s, 0, (in.flags & RT_FLAG_COUNTERS) != 0, a);
   HIP_TRY(hipEventRecord(f.end, stream));
   HIP_TRY(hipGetLastError());
-  f.primary = primary;
+  f.primary = primary * (uint64_t)n_frames;
+  f.frames = (uint32_t)n_frames;
   f.pending = true;
   return RT_OK;
 }

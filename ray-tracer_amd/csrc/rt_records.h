@@ -28,6 +28,18 @@ struct CameraDev {
   uint32_t tile_h, tile_shift;
 };
 
+// The frames of one launch of the camera-ray kernel beyond its first (rt_render_frames): frame k > 0 is seen through
+// cam[k - 1] and written to rgb8[k - 1]; the canvas, the part and its tiles are those of the first.  A part of a
+// frame is a short launch that ends with its slowest wave; several frames' worth of it fill the GPU as a whole
+// frame does.
+constexpr int MAX_LAUNCH_FRAMES = 8;
+struct FrameBatch {
+  uint32_t frames;           // 0 or 1: one frame
+  uint32_t waves_per_frame;  // the grid is frames x this many workgroups
+  uint8_t* rgb8[MAX_LAUNCH_FRAMES - 1];
+  CameraDev cam[MAX_LAUNCH_FRAMES - 1];
+};
+
 struct ImageOut {
   uint8_t* rgb8;
   double* rgb64;
@@ -62,6 +74,7 @@ struct GenLaunch {
   uint32_t segcap = 0;                     // (null: the rays are dense, n of them)
   // where the shadow queries of hits on a cone's extension go (segcap 0: nowhere, they are walked in place)
   ShadowView aside{};
+  FrameBatch batch{};  // mode 0 only
 };
 
 constexpr int TILE = 32;  // multi-GPU partition granule: pixels per side of a tile, rows of a band unless the caller asks for 16 or 8

@@ -91,7 +91,7 @@ struct rt_scene {
   hipStream_t last_stream = nullptr;   // where the most recent frame was enqueued
   hipStream_t copy_stream = nullptr;   // rt_download
   hipEvent_t copy_order = nullptr, copy_order2[FRAME_STREAMS - 1] = {nullptr, nullptr, nullptr};
-  static constexpr int COPY_FENCES = 8;
+  static constexpr int COPY_FENCES = 16;
   hipEvent_t copy_fence[COPY_FENCES] = {};  // rt_copy_fence / rt_copy_wait
   bool copy_fence_set[COPY_FENCES] = {};
   rt::SceneDev dev{};
@@ -147,6 +147,7 @@ struct rt_scene {
     hipEvent_t begin = nullptr, end = nullptr;
     bool pending = false;
     uint64_t primary = 0;
+    uint32_t frames = 1;  // frames the launch rendered (rt_render_frames)
   };
   // Counters of the asynchronous frames: every such frame adds to the same device words (nothing per frame
   // crosses PCIe or needs a launch of its own); they are read and cleared when the frames are collected.
@@ -253,6 +254,8 @@ CameraDev camera_dev(const rt_camera* c);
 int run_pipeline(rt_scene* s, const PipelineIn& in, rt_stats* stats);
 // One camera frame of a scene that spawns no rays: a single kernel, only enqueued.
 int enqueue_direct_frame(rt_scene* s, const PipelineIn& in, uint64_t primary);
+int enqueue_direct_frames(rt_scene* s, const PipelineIn& in, uint64_t primary, int n_frames, const CameraDev* more_cams,
+                          uint8_t* const* more_rgb8);
 // One camera frame of a scene that spawns rays, only enqueued: possible when the last frame's queue lengths are
 // known for this job (*enqueued; otherwise the caller renders it with run_pipeline).
 int enqueue_speculative_frame(rt_scene* s, const PipelineIn& in, uint64_t primary, bool* enqueued);

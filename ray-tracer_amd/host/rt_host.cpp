@@ -1178,7 +1178,7 @@ void parallel_render(const World& world, const Camera& camera, size_t jobs, cons
 FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth, const Share& share)
     : devices_(devices), depth_(depth) {
   if (devices.empty()) throw Panic("assertion failed: size > 0");  // src/parallel.rs:94
-  if (depth < 1 || depth > 8) throw std::invalid_argument("FrameLoop: depth must lie in 1..8");
+  if (depth < 1 || depth > 16) throw std::invalid_argument("FrameLoop: depth must lie in 1..16");
   first_part_ = share.first_part;
   total_parts_ = share.total_parts ? share.total_parts : devices.size();
   if (first_part_ + devices.size() > total_parts_) throw std::invalid_argument("FrameLoop: more parts than the frame has");
@@ -1199,18 +1199,22 @@ FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector
     check_rt(rt_scene_create(&desc, devices[0], &scenes_[0]));
     check_rt(rt_scene_footprint(scenes_[0], nullptr, &build_seconds_));
     for (size_t k = 1; k < devices.size(); k++) check_rt(rt_scene_clone(scenes_[0], devices[k], &scenes_[k]));
-    for (int k = 0; k < depth; k++) {
-      uint8_t* p = own_ring_ ? (uint8_t*)rt_host_alloc(frame_bytes_) : share.ring + (size_t)k * frame_bytes_;
-      if (!p) throw std::runtime_error("FrameLoop: no page-locked host memory for the frame ring");
-      host_.push_back(p);
+    frame_stride_ = frame_bytes_;
+    if (own_ring_ && total_parts_ > 1) {
+      const size_t round_bytes = total_parts_ * band_rows_ * cam_.hsize * 3;  // one band of every part
+      frame_stride_ = (frame_bytes_ + round_bytes - 1) / round_bytes * round_bytes;
     }
+    if (own_ring_) {
+      host_block_ = (uint8_t*)rt_host_alloc((size_t)depth * frame_stride_);
+      if (!host_block_) throw std::runtime_error("FrameLoop: no page-locked host memory for the frame ring");
+    }
+    for (int k = 0; k < depth; k++) host_.push_back((own_ring_ ? host_block_ : share.ring) + (size_t)k * frame_stride_);
     dev_frames_.resize(devices.size());
-    for (size_t k = 0; k < devices.size(); k++)
-      for (int j = 0; j < depth; j++) {
-        void* p = nullptr;
-        check_rt(rt_device_alloc(devices[k], frame_bytes_, &p));
-        dev_frames_[k].push_back((uint8_t*)p);
-      }
+    for (size_t k = 0; k < devices.size(); k++) {
+      void* p = nullptr;
+      check_rt(rt_device_alloc(devices[k], (size_t)depth * frame_stride_, &p));
+      for (int j = 0; j < depth; j++) dev_frames_[k].push_back((uint8_t*)p + (size_t)j * frame_stride_);
+    }
   } catch (...) {
     release();
     throw;
@@ -1219,12 +1223,12 @@ FrameLoop::FrameLoop(const World& world, const Camera& camera, const std::vector
 
 void FrameLoop::release() {
   for (size_t k = 0; k < dev_frames_.size(); k++)
-    for (uint8_t* p : dev_frames_[k]) rt_device_free(devices_[k], p);
+    if (!dev_frames_[k].empty()) rt_device_free(devices_[k], dev_frames_[k][0]);
   dev_frames_.clear();
   for (rt_scene* s : scenes_) rt_scene_destroy(s);
   scenes_.clear();
-  if (own_ring_)
-    for (uint8_t* p : host_) rt_host_free(p);
+  if (host_block_) rt_host_free(host_block_);
+  host_block_ = nullptr;
   host_.clear();
 }
 
@@ -1257,6 +1261,18 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
   size_t stride = depth_ >= 3 ? 2 : 1;
   if (const char* e = getenv("RT_AMD_COPIES_PER_FENCE")) stride = (size_t)std::max(1, atoi(e));
   stride = std::min(stride, (size_t)std::max(1, depth_ - 1));
+  // Frames per launch.  A part of a frame alone is a short launch that ends with its slowest wave while most of the
+  // GPU idles; several frames of the part in one launch (rt_render_frames) fill it as a whole frame does.  Three
+  // launches or more are to be in flight (one renders, one is being copied, one waits for its slots), so a launch
+  // takes at most a third of the ring, and a count that divides the ring keeps a launch's slots in one piece
+  // (one GPU rendering an eighth of the teapot frame at 1080p, ms per frame on the host: 0.034 one at a time in a
+  // ring of 8, 0.024 two at a time, 0.019 four at a time in a ring of 16; four at a time in a ring of 8: 0.028).
+  size_t group = spawns_ || n < 2 ? 1 : 4;
+  const bool asked = getenv("RT_AMD_FRAMES_PER_LAUNCH") != nullptr;
+  if (asked) group = (size_t)std::max(1, atoi(getenv("RT_AMD_FRAMES_PER_LAUNCH")));
+  group = spawns_ ? 1 : std::max<size_t>(1, std::min({group, (size_t)depth_ / (asked ? 2 : 3), (size_t)RT_MAX_FRAMES_PER_CALL}));
+  while ((size_t)depth_ % group) group--;
+  frames_per_launch_ = group;
   auto worker = [&](size_t k) {
     rt_scene* sc = scenes_[k];
     const size_t part = first_part_ + k;
@@ -1264,22 +1280,45 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     std::vector<int> fenced_by((size_t)depth_, -1);  // per slot: the slot whose fence covers this slot's last copy
     std::vector<int> unfenced;                        // slots copied since the last fence
     size_t last_frame = 0;                            // of the stretch of frames being enqueued
-    auto render_part = [&](size_t f) {
+    auto render_part = [&](size_t f, size_t count) {  // frames f .. f + count - 1 in one launch
       if (!ok) return;
-      const int slot = (int)(f % (size_t)depth_);
-      uint8_t* dev = dev_frames_[k][(size_t)slot];
-      // the copy that last read this device frame (depth frames ago) must be through before it is rendered over
-      if (to_host && fenced_by[(size_t)slot] >= 0 && rt_copy_wait(sc, (uint32_t)fenced_by[(size_t)slot]) != RT_OK) ok = false;
-      if (ok && rt_render(sc, &cam_, (int)part, (int)n, RT_FLAG_ASYNC | part_flags, dev, nullptr, nullptr, nullptr) != RT_OK) ok = false;
+      rt_camera cams[RT_MAX_FRAMES_PER_CALL];
+      uint8_t* devs[RT_MAX_FRAMES_PER_CALL];
+      for (size_t j = 0; j < count && ok; j++) {
+        const int slot = (int)((f + j) % (size_t)depth_);
+        cams[j] = cam_;
+        devs[j] = dev_frames_[k][(size_t)slot];
+        // the copy that last read this device frame (depth frames ago) must be through before it is rendered over
+        if (to_host && fenced_by[(size_t)slot] >= 0 && rt_copy_wait(sc, (uint32_t)fenced_by[(size_t)slot]) != RT_OK) ok = false;
+      }
+      if (ok && count == 1 && rt_render(sc, &cam_, (int)part, (int)n, RT_FLAG_ASYNC | part_flags, devs[0], nullptr, nullptr, nullptr) != RT_OK)
+        ok = false;
+      if (ok && count > 1 && rt_render_frames(sc, cams, (int)count, (int)part, (int)n, RT_FLAG_ASYNC | part_flags, devs) != RT_OK) ok = false;
       if (!ok) errors[k] = rt_last_error();
     };
-    auto copy_part = [&](size_t f) {
+    // The frames of one launch, in consecutive slots of a padded ring: every band of this part in all of them with one
+    // strided copy (whole bands: what lies beyond the image's last row is padding on both sides).
+    const bool one_copy_per_launch = frame_stride_ != frame_bytes_;
+    auto copy_launch = [&](size_t f, size_t count) {
+      if (!ok || !to_host) return;
+      const int slot = (int)(f % (size_t)depth_);
+      const size_t rounds = frame_stride_ / (n * band_bytes), off = part * band_bytes;
+      if (rt_download_2d(sc, dev_frames_[k][(size_t)slot] + off, host_[(size_t)slot] + off, band_bytes, count * rounds, n * band_bytes, nullptr) != RT_OK)
+        ok = false;
+      const int last = slot + (int)count - 1;
+      if (ok && rt_copy_fence(sc, (uint32_t)last) != RT_OK) ok = false;
+      for (int s : unfenced) fenced_by[(size_t)s] = last;
+      unfenced.clear();
+      for (size_t j = 0; j < count; j++) fenced_by[(size_t)slot + j] = last;
+      if (!ok) errors[k] = rt_last_error();
+    };
+    auto copy_part = [&](size_t f, bool last_of_launch) {
       if (!ok || !to_host) return;
       const int slot = (int)(f % (size_t)depth_);
       uint8_t* dev = dev_frames_[k][(size_t)slot];
       auto fence = [&]() {  // after this slot's copy has been enqueued
         unfenced.push_back(slot);
-        if (unfenced.size() < stride && f != last_frame) return;
+        if (unfenced.size() < stride && f != last_frame && !(last_of_launch && group > 1)) return;
         if (rt_copy_fence(sc, (uint32_t)slot) != RT_OK) ok = false;
         for (int s : unfenced) fenced_by[(size_t)s] = slot;
         unfenced.clear();
@@ -1309,12 +1348,18 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     // other scenes need no such look and are copied as soon as they are enqueued.
     const bool copy_one_late = spawns_ && to_host && depth_ >= 2;
     auto stretch = [&](size_t first_f, size_t count) {
-      for (size_t f = first_f; f < first_f + count; f++) {
-        render_part(f);
-        if (!copy_one_late) copy_part(f);
-        else if (f > first_f) copy_part(f - 1);
+      for (size_t f = first_f; f < first_f + count; f += group) {
+        const size_t g = std::min(group, first_f + count - f);
+        render_part(f, g);
+        if (copy_one_late) {  // group == 1
+          if (f > first_f) copy_part(f - 1, false);
+        } else if (one_copy_per_launch && f % (size_t)depth_ + g <= (size_t)depth_) {
+          copy_launch(f, g);
+        } else {
+          for (size_t j = 0; j < g; j++) copy_part(f + j, j + 1 == g);
+        }
       }
-      if (copy_one_late && count > 0) copy_part(first_f + count - 1);
+      if (copy_one_late && count > 0) copy_part(first_f + count - 1, false);
     };
     last_frame = warmup ? warmup - 1 : 0;
     stretch(0, warmup);

@@ -153,7 +153,7 @@ class FrameLoop {
     uint8_t* ring = nullptr;                 // nullptr: the loop allocates its own ring
   };
   // devices[k]: GPU of part k (the same GPU may serve several parts).  depth: frames in flight per worker
-  // and host frames in the ring (1..8).
+  // and host frames in the ring (1..16).
   FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth, const Share& share);
   FrameLoop(const World& world, const Camera& camera, const std::vector<int>& devices, int depth)
       : FrameLoop(world, camera, devices, depth, Share()) {}
@@ -177,9 +177,16 @@ class FrameLoop {
   rt_camera cam_{};
   std::vector<int> devices_;
   std::vector<rt_scene*> scenes_;
-  std::vector<std::vector<uint8_t*>> dev_frames_;  // [part][slot], on the part's GPU
+  std::vector<std::vector<uint8_t*>> dev_frames_;  // [part][slot], on the part's GPU: one block per part, slots frame_stride_ apart
   std::vector<uint8_t*> host_;                     // [slot], page-locked, shared by all parts
+  uint8_t* host_block_ = nullptr;                  // the loop's own ring: one block, slots frame_stride_ apart
   size_t frame_bytes_ = 0;
+  // Bytes from one slot to the next, in the device blocks and in the loop's own ring.  A ring of the loop's own is
+  // padded to whole rounds of bands (a multiple of parts x band bytes): the bands of one part then lie at one pitch
+  // through consecutive slots, and the frames of one launch go to the host with one strided copy (a copy costs about
+  // 8 us whatever it moves, as much as an eighth of a 1080p frame takes on the link).  A caller's ring has its
+  // frames back to back, and every frame is copied by itself.
+  size_t frame_stride_ = 0;
   size_t first_part_ = 0, total_parts_ = 0;
   bool own_ring_ = true;
   int depth_ = 0;
@@ -188,10 +195,12 @@ class FrameLoop {
   // bands of 8 rows, 1.29 times with 32) and one strided copy still moves a part
   size_t band_rows_ = 8;
   bool spawns_ = false;  // some material reflects or refracts: a frame is several generations of rays
+  size_t frames_per_launch_ = 1;  // of the last run()
   uint32_t band_flags() const;
 
  public:
   size_t band_rows() const { return band_rows_; }
+  size_t frames_per_launch() const { return frames_per_launch_; }  // what the last run() used (rt_render_frames)
 
  private:
   double build_seconds_ = 0;

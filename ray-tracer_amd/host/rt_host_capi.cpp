@@ -255,6 +255,7 @@ void rth_frame_loop_info(rth_frame_loop* l, uint64_t* out, double* build_seconds
 
 // rows of a band of this loop's parts (32 unless RT_AMD_BAND_ROWS asked for 16 or 8 when the loop was made)
 uint64_t rth_frame_loop_band_rows(rth_frame_loop* l) { return l->loop->band_rows(); }
+uint64_t rth_frame_loop_frames_per_launch(rth_frame_loop* l) { return l->loop->frames_per_launch(); }
 
 uint64_t rth_ppm_encode(uint64_t w, uint64_t hh, const uint8_t* rgb8, char* buf, uint64_t cap) {
   std::string s = ppm_encode(w, hh, rgb8);

@@ -122,6 +122,8 @@ extern "C" {
     pub fn rt_render(scene: *mut rt_scene, camera: *const rt_camera, part: c_int, n_parts: c_int, flags: u32,
                      rgb8_dev: *mut u8, rgb64_dev: *mut f64, hit_leaf_dev: *mut i32, stats: *mut rt_stats) -> c_int;
     pub fn rt_scene_wait(scene: *mut rt_scene, total: *mut rt_stats) -> c_int;
+    pub fn rt_render_frames(scene: *mut rt_scene, cameras: *const rt_camera, n_frames: c_int, part: c_int, n_parts: c_int,
+                            flags: u32, rgb8_dev: *const *mut u8) -> c_int;
     pub fn rt_scene_stream(scene: *mut rt_scene, hip_stream: *mut *mut c_void) -> c_int;
     pub fn rt_download(scene: *mut rt_scene, src_dev: *const c_void, dst_host: *mut c_void, bytes: u64,
                        after_stream: *mut c_void) -> c_int;

@@ -36,9 +36,9 @@ for t in trace_hbm trace_host; do f=$(find $O/$t -name "*kernel_stats.csv" -prin
 rm -rf $O/trace_hbm $O/trace_host $O/pmc $O/pmc_traffic
 ls $O
 # what one GPU of an N-GPU run does (part 0..N-1 of N alone on this GPU), copy rates, host registration
-timeout -k 10 300 python3 tools/part_period.py > $O/part_period.txt 2>&1 || { echo "part_period failed"; exit 1; }
-# the same with eight frames in flight (what bench.py uses for four parts or more), bands of 8 rows
-timeout -k 10 200 python3 tools/part_period.py 8 8 > $O/part_period_depth8.txt 2>&1 || { echo "part_period (depth 8) failed"; exit 1; }
+timeout -k 10 300 python3 tools/part_period.py 0 8 > $O/part_period.txt 2>&1 || { echo "part_period failed"; exit 1; }
+# the same with one frame per launch and copy in a ring of eight (what the loop did before it launched several at once)
+RT_AMD_FRAMES_PER_LAUNCH=1 timeout -k 10 200 python3 tools/part_period.py 8 8 > $O/part_period_one_frame_per_launch.txt 2>&1 || { echo "part_period (one frame per launch) failed"; exit 1; }
 if [ -x ray-tracer_amd/lib/d2h_probe ]; then timeout -k 10 100 ray-tracer_amd/lib/d2h_probe > $O/d2h_probe.txt 2>&1 || exit 1; fi
 if [ -x ray-tracer_amd/lib/register_probe ]; then timeout -k 10 100 ray-tracer_amd/lib/register_probe > $O/register_probe.txt 2>&1 || exit 1; fi
 # the launcher path, two ranks on this one GPU (gloo for the barriers): a rehearsal, no scaling figure

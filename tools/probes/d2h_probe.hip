@@ -91,5 +91,29 @@ int main() {
       }
     }
   }
+  // the same for bands of 8 rows (what the frame loop deals), the copies of consecutive frames going round-robin
+  // to one, two or three copy streams: does the fixed cost of one copy overlap the transfer of the next?
+  {
+    hipStream_t copy[3];
+    for (auto& c : copy) CK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    const size_t band = 8 * 1920 * 3;
+    for (int n : {2, 4, 8}) {
+      const size_t bands = (1080 / 8 + n - 1) / n;
+      for (int streams = 1; streams <= 3; streams++) {
+        for (int rep = 0; rep < 2; rep++) {
+          CK(hipDeviceSynchronize());
+          auto t0 = std::chrono::steady_clock::now();
+          for (int f = 0; f < frames; f++) {
+            size_t slot = (f & 3) * bytes;
+            CK(hipMemcpy2DAsync(host + slot, n * band, dev + slot, n * band, band, bands, hipMemcpyDeviceToHost, copy[f % streams]));
+          }
+          CK(hipDeviceSynchronize());
+          double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
+          if (rep) printf("%d parts, %zu bands of %zu bytes, one strided copy per frame, %d copy stream(s): %.4f ms per frame, %.1f GB/s\n", n, bands,
+                          band, streams, ms, band * bands / ms * 1e-6);
+        }
+      }
+    }
+  }
   return 0;
 }
