@@ -78,6 +78,8 @@ extern "C" int rt_device_alloc(int device, uint64_t bytes, void** out) {
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
   if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+  // the fill returns before it is done, and streams that do not wait for the null stream could write the memory first
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   (void)hipSetDevice(previous);
   if (e != hipSuccess) {
     if (p) (void)hipFree(p);

@@ -173,7 +173,10 @@ int collect_all(rt_scene* s) {
   }
   if (!s->async_counters_dirty) return RT_OK;
   HIP_TRY(hipMemcpy(s->h_async_stats, s->d_async_stats, STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  // hipMemset of device memory returns before it is done, and the null stream it runs on does not hold back the
+  // scene's streams: without the wait the fill could land after the next frame's kernel has added its counts
   HIP_TRY(hipMemset(s->d_async_stats, 0, STAT_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   s->async_counters_dirty = false;
 #ifdef RT_STAMPS
   {

@@ -607,6 +607,7 @@ static int scene_runtime_init(rt_scene* s, int device) {
   { int rc = ensure_depth(s, RECURSION_DEPTH); if (rc) return rc; }
   HIP_TRY(hipMalloc((void**)&s->d_async_stats, STAT_WORDS * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(s->d_async_stats, 0, STAT_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(hipStreamSynchronize(nullptr));  // the fill is asynchronous and the scene's streams do not wait for the null stream
   HIP_TRY(hipHostMalloc((void**)&s->h_async_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
   for (rt_scene::FrameSlot& f : s->slots) {
     HIP_TRY(hipEventCreate(&f.begin));
