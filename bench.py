@@ -45,16 +45,19 @@ RECORD_BYTES = 13 * 8 + 4 * 4  # one ray record of a generation buffer
 DEPTH = int(os.environ.get("RT_BENCH_DEPTH", "4"))  # frames in flight per GPU = host frames in the ring
 
 
-def ring_depth(parts):
+def ring_depth(parts, steps=200):
     """Frames in flight per GPU.  A part of the frame is a short launch that lasts as long as its slowest wave whatever
-    else the GPU could do, and a copy costs about 8 us whatever it moves: the loop therefore renders four frames of a
-    part with one launch and moves them with one copy, and keeps four such launches in flight (tools/part_period.py,
-    one GPU rendering its part of N, ms per frame on the host: N = 2 0.070 -> 0.061, N = 4 0.043 -> 0.033, N = 8
-    0.034 -> 0.019 against one frame per launch in a ring of eight).  Whole frames are bound by their copy, and eight
-    host frames of 6.2 MB fall out of the host's last-level cache (0.124 -> 0.160 ms per frame at N = 1)."""
+    else the GPU could do, and a copy costs about 8 us whatever it moves: the loop therefore renders several frames of
+    a part with one launch and moves them with one copy, a third of the ring at most and four at most
+    (FrameLoop::run), and ramps the launch size up and down at the ends of a stretch.  A ring of 12 or 16 (four frames
+    per launch, three or four launches in flight) is the fastest in the long run, a ring of 8 (two per launch, four in
+    flight) over a short timed region, where filling and draining the pipeline counts (tools/part_period.py and the
+    sweeps in profiles/: one GPU rendering its part of N, ms per frame on the host, 200 / 20 timed frames: N = 1
+    0.117 / 0.149 with 12 and 0.120 / 0.136 with 8, against 0.129 / 0.138 one frame per launch in a ring of 4; N = 8
+    0.020 / 0.029 and 0.024 / 0.031 against 0.034 / 0.040; 16 against 12 in the long run: N = 8 0.019 against 0.022)."""
     if "RT_BENCH_DEPTH" in os.environ:
         return DEPTH
-    return 16 if parts >= 2 else 4
+    return 16 if steps >= 64 else 8
 # Untimed frames before the warmup, as a stretch of their own that ends with every GPU idle.  A fresh process pays
 # about 20 ms once: code objects and runtime pools with the first launches, and about 5.6 ms for each of three DMA
 # engines on that engine's first copy -- the runtime turns to a second and third engine only when a copy finds the
@@ -110,7 +113,11 @@ def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
     plan_bytes = rays * (2 * 80 + 2 * 32) + nv * 64 + tt * 72 + qt * 136 + hits * (24 + 200) + launches * scene_bytes
     avg_ms = piped["kernel_ms"] / max(1, piped["kernel_launches"])
     lone_ms = lone["kernel_ms"] / max(1, lone["kernel_launches"])
-    per_launch = flops_survey / launches
+    # A launch of the timed loop renders several frames of its part (rt_render_frames): per launch means per that many
+    # frames.  The instrumented frame and the lone launches are one frame per launch.
+    fpl = (piped["primary"] / max(1, counted["primary"])) * launches / max(1, piped["kernel_launches"])
+    per_frame_launch = flops_survey / launches
+    per_launch = per_frame_launch * fpl
     # Counter figures collected by separate rocprofv3 --pmc runs of this bench (tools/gpu_round.sh) and kept under
     # profiles/: quoted only while the kernel sources they were collected on are the ones in this tree.
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -130,18 +137,22 @@ def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
         for k in keys:
             counters[k] = doc.get("k_generation", {}).get(k)
     pmc, traffic = counters.get("f64_ops_per_launch"), counters.get("hbm_bytes_per_launch")
+    if pmc:
+        pmc *= fpl      # the counter runs launch one frame at a time (tools/gpu_round.sh)
+    if traffic:
+        traffic *= fpl  # an upper bound: frames of one launch read the scene once between them
     frac = per_launch / (avg_ms * 1e-3) / FP64_VALU_PEAK
     return {
         "bound": "fp64_valu", "achieved": per_launch / (avg_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK / 1e12,
         "unit": "TFLOP/s", "frac": frac, "traffic": traffic,
-        "kernel": "k_generation", "launches_per_frame": launches, "avg_launch_ms": avg_ms, "lone_launch_ms": lone_ms,
-        "flops_per_launch": per_launch,
-        "frac_lone_launch": per_launch / (lone_ms * 1e-3) / FP64_VALU_PEAK,
+        "kernel": "k_generation", "launches_per_frame": launches, "frames_per_launch": fpl, "avg_launch_ms": avg_ms,
+        "lone_launch_ms": lone_ms, "flops_per_launch": per_launch, "flops_per_launch_of_one_frame": per_frame_launch,
+        "frac_lone_launch": per_frame_launch / (lone_ms * 1e-3) / FP64_VALU_PEAK,
         # all GPUs together over the frame period: what the node delivers while launches overlap
         "frac_per_frame_period": flops_survey / frame_period_s / (FP64_VALU_PEAK * n_parts),
-        "f64_flops_per_launch_this_implementation": flops_f64 / launches,
-        "frac_f64_this_implementation": flops_f64 / launches / (avg_ms * 1e-3) / FP64_VALU_PEAK,
-        "f32_box_test_ops_per_launch": f32_ops / launches,
+        "f64_flops_per_launch_this_implementation": flops_f64 / launches * fpl,
+        "frac_f64_this_implementation": flops_f64 / launches * fpl / (avg_ms * 1e-3) / FP64_VALU_PEAK,
+        "f32_box_test_ops_per_launch": f32_ops / launches * fpl,
         "pmc_f64_ops_per_launch": pmc,
         "frac_pmc_f64": None if not pmc else pmc / (avg_ms * 1e-3) / FP64_VALU_PEAK,
         # the ceilings that bind this kernel, from the same counter runs (lone launches under the profiler)
@@ -149,18 +160,19 @@ def roofline_of(counted, lone, piped, scene_bytes, frame_period_s, n_parts):
         "active_lane_share": counters.get("active_lane_share"),
         "counters_note": ("profiles/%s were collected on other kernel sources than this tree's: not quoted" % " and ".join(stale)) if stale
                          else "traffic and counter figures: profiles/traffic.json, profiles/pmc_f64.json, collected on this tree's kernel sources",
-        "hbm_bytes_per_launch": hbm / launches, "frac_hbm": hbm / launches / (avg_ms * 1e-3) / HBM_PEAK,
-        "plan_bytes_per_launch": plan_bytes / launches,
-        "plan_bytes_over_hbm_peak": plan_bytes / launches / (avg_ms * 1e-3) / HBM_PEAK,
+        "hbm_bytes_per_launch": hbm / launches * fpl, "frac_hbm": hbm / launches * fpl / (avg_ms * 1e-3) / HBM_PEAK,
+        "plan_bytes_per_launch": plan_bytes / launches * fpl,
+        "plan_bytes_over_hbm_peak": plan_bytes / launches * fpl / (avg_ms * 1e-3) / HBM_PEAK,
         "events_per_frame": {"node_visits": nv, "tri_tests": tt, "quadric_tests": qt, "gate_tests": gt, "shaded_hits": hits},
         "coefficients": {"frac": SURVEY, "f64_this_implementation": F64, "f32_per_node_visit": F32_PER_NODE},
         "note": "no dense contraction on this path, so no MFMA: the ceiling is vector FP64 (78.6 TFLOP/s datasheet, an FMA "
                 "counted as two; the path is compiled without contraction to match the reference bit for bit, so half of "
                 "that is reachable). frac prices the events of one instrumented frame with the plan's coefficients "
-                "(node 22, triangle 46, quadric 60, shaded hit 150) over avg_launch_ms, the mean k_generation duration of "
-                "the timed loop from HIP events on the library's streams; launches of consecutive frames overlap on two "
-                "streams, so avg_launch_ms exceeds both lone_launch_ms and the frame period (profiles/ holds the kernel "
-                "timeline). hbm_bytes_per_launch is the traffic the algorithm cannot avoid (scene once, pixels, ray "
+                "(node 22, triangle 46, quadric 60, shaded hit 150), times the frames a launch of the timed loop renders "
+                "(frames_per_launch), over avg_launch_ms, the mean k_generation duration of the timed loop from HIP events "
+                "on the library's streams; consecutive launches overlap on two streams, so avg_launch_ms exceeds the "
+                "frame period times frames_per_launch (profiles/ holds the kernel timeline); lone_launch_ms is one "
+                "frame by itself. hbm_bytes_per_launch is the traffic the algorithm cannot avoid (scene once, pixels, ray "
                 "records); the per-visit record fetches are cache hits.",
     }
 
@@ -186,7 +198,7 @@ def bench_single_process(args, timed=None):
     t_load = time.perf_counter()
     scene = pkg.Scene.from_file(args.scene, base_dir=ROOT, device=None)  # host side only; the loop owns the GPU copies
     scene.set_canvas(W, H)
-    depth = ring_depth(n)
+    depth = ring_depth(n, args.steps)
     loop = scene.frame_loop(devices, depth=depth)
     load_s = time.perf_counter() - t_load
     info, linfo = scene.info(), loop.info()

@@ -1262,12 +1262,15 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
   if (const char* e = getenv("RT_AMD_COPIES_PER_FENCE")) stride = (size_t)std::max(1, atoi(e));
   stride = std::min(stride, (size_t)std::max(1, depth_ - 1));
   // Frames per launch.  A part of a frame alone is a short launch that ends with its slowest wave while most of the
-  // GPU idles; several frames of the part in one launch (rt_render_frames) fill it as a whole frame does.  Three
-  // launches or more are to be in flight (one renders, one is being copied, one waits for its slots), so a launch
-  // takes at most a third of the ring, and a count that divides the ring keeps a launch's slots in one piece
-  // (one GPU rendering an eighth of the teapot frame at 1080p, ms per frame on the host: 0.034 one at a time in a
-  // ring of 8, 0.024 two at a time, 0.019 four at a time in a ring of 16; four at a time in a ring of 8: 0.028).
-  size_t group = spawns_ || n < 2 ? 1 : 4;
+  // GPU idles; several frames of the part in one launch (rt_render_frames) fill it as a whole frame does, and one
+  // copy for them all pays the fixed cost of a copy once (whole frames gain by that alone).  Three launches or more
+  // are to be in flight (one renders, one is being copied, one waits for its slots), so a launch takes at most a
+  // third of the ring, and a count that divides the ring keeps a launch's slots in one piece (one GPU rendering an
+  // eighth of the teapot frame at 1080p, ms per frame on the host: 0.034 one at a time in a ring of 8, 0.024 two at
+  // a time, 0.019 four at a time in a ring of 12 or 16; four at a time in a ring of 8: 0.028).  More than four
+  // launches in flight are no help and for whole frames a loss (a ring of 8 one frame at a time: 0.29 ms per frame
+  // against 0.128 in a ring of 4; a ring of 12 two at a time: 0.23 against 0.120 in a ring of 8).
+  size_t group = spawns_ ? 1 : 4;
   const bool asked = getenv("RT_AMD_FRAMES_PER_LAUNCH") != nullptr;
   if (asked) group = (size_t)std::max(1, atoi(getenv("RT_AMD_FRAMES_PER_LAUNCH")));
   group = spawns_ ? 1 : std::max<size_t>(1, std::min({group, (size_t)depth_ / (asked ? 2 : 3), (size_t)RT_MAX_FRAMES_PER_CALL}));
@@ -1279,6 +1282,24 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     bool ok = true;
     std::vector<int> fenced_by((size_t)depth_, -1);  // per slot: the slot whose fence covers this slot's last copy
     std::vector<int> unfenced;                        // slots copied since the last fence
+    // At most three fenced copies (or pairs of copies) wait in the copy stream: the worker holds back a fourth until
+    // the oldest has gone through.  With more of them queued the same loop runs in one of two states, from one run
+    // to the next and within a run -- whole frames four per launch in a ring of 16: 0.119 or 0.127-0.131 ms per
+    // frame (0.156-0.160 in some processes), two per launch in a ring of 8: 0.121 or 0.125-0.129 (0.163) -- and with
+    // the limit only in the fast one (0.1190-0.1193 and 0.1210-0.1213, twelve runs each).  Two are too few for
+    // launches of four frames (0.127-0.129: the host's turn-around shows), one for any (0.142).
+    std::vector<int> fences_out;  // slots whose fence was recorded and not yet waited for, oldest first
+    auto fence_out = [&](int slot) {
+      // a slot is fenced again only after its last fence was waited for (the ring): an older entry of it is done
+      fences_out.erase(std::remove(fences_out.begin(), fences_out.end(), slot), fences_out.end());
+      fences_out.push_back(slot);
+    };
+    auto make_room = [&]() {
+      while (ok && fences_out.size() >= 3) {
+        if (rt_copy_wait(sc, (uint32_t)fences_out.front()) != RT_OK) ok = false;
+        fences_out.erase(fences_out.begin());
+      }
+    };
     size_t last_frame = 0;                            // of the stretch of frames being enqueued
     auto render_part = [&](size_t f, size_t count) {  // frames f .. f + count - 1 in one launch
       if (!ok) return;
@@ -1298,15 +1319,22 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     };
     // The frames of one launch, in consecutive slots of a padded ring: every band of this part in all of them with one
     // strided copy (whole bands: what lies beyond the image's last row is padding on both sides).
-    const bool one_copy_per_launch = frame_stride_ != frame_bytes_;
+    // (Whole frames lie back to back in any ring: one plain copy.)
+    const bool one_copy_per_launch = n == 1 || frame_stride_ % (n * band_bytes) == 0;
     auto copy_launch = [&](size_t f, size_t count) {
       if (!ok || !to_host) return;
       const int slot = (int)(f % (size_t)depth_);
       const size_t rounds = frame_stride_ / (n * band_bytes), off = part * band_bytes;
-      if (rt_download_2d(sc, dev_frames_[k][(size_t)slot] + off, host_[(size_t)slot] + off, band_bytes, count * rounds, n * band_bytes, nullptr) != RT_OK)
+      make_room();
+      if (n == 1) {
+        if (rt_download(sc, dev_frames_[k][(size_t)slot], host_[(size_t)slot], count * frame_bytes_, nullptr) != RT_OK) ok = false;
+      } else if (rt_download_2d(sc, dev_frames_[k][(size_t)slot] + off, host_[(size_t)slot] + off, band_bytes, count * rounds, n * band_bytes,
+                                nullptr) != RT_OK) {
         ok = false;
+      }
       const int last = slot + (int)count - 1;
       if (ok && rt_copy_fence(sc, (uint32_t)last) != RT_OK) ok = false;
+      fence_out(last);
       for (int s : unfenced) fenced_by[(size_t)s] = last;
       unfenced.clear();
       for (size_t j = 0; j < count; j++) fenced_by[(size_t)slot + j] = last;
@@ -1320,9 +1348,11 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
         unfenced.push_back(slot);
         if (unfenced.size() < stride && f != last_frame && !(last_of_launch && group > 1)) return;
         if (rt_copy_fence(sc, (uint32_t)slot) != RT_OK) ok = false;
+        fence_out(slot);
         for (int s : unfenced) fenced_by[(size_t)s] = slot;
         unfenced.clear();
       };
+      if (unfenced.empty()) make_room();  // before the first copy of a new fenced group
       if (n == 1) {  // the whole frame is this part's: one contiguous copy
         if (rt_download(sc, dev, host_[(size_t)slot], frame_bytes_, nullptr) != RT_OK) ok = false;
         if (ok) fence();
@@ -1348,8 +1378,11 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     // other scenes need no such look and are copied as soon as they are enqueued.
     const bool copy_one_late = spawns_ && to_host && depth_ >= 2;
     auto stretch = [&](size_t first_f, size_t count) {
-      for (size_t f = first_f; f < first_f + count; f += group) {
-        const size_t g = std::min(group, first_f + count - f);
+      // a stretch starts and ends with small launches: the first copy need not wait for four frames, and the last
+      // copy, which nothing overlaps, is a short one
+      for (size_t f = first_f, g = 1; f < first_f + count; f += g) {
+        const size_t left = first_f + count - f;
+        g = std::min({group, f - first_f + 1, (left + 1) / 2});
         render_part(f, g);
         if (copy_one_late) {  // group == 1
           if (f > first_f) copy_part(f - 1, false);

@@ -94,7 +94,7 @@ def test_refusals(pkg, root):
     scene.wait()
 
 
-@pytest.mark.parametrize("parts,depth,per_launch", [(2, 8, 2), (4, 16, 4), (8, 12, 4), (3, 9, 3), (4, 3, 1), (1, 8, 1)])
+@pytest.mark.parametrize("parts,depth,per_launch", [(2, 8, 2), (4, 16, 4), (8, 12, 4), (3, 9, 3), (4, 3, 1), (1, 8, 2), (1, 12, 4)])
 def test_the_frame_loop_launches_several_frames_of_a_part_at_once(pkg, root, parts, depth, per_launch):
     path = os.path.join(root, "scenes", "teapot.json")
     whole = pkg.Scene.from_file(path, base_dir=root, device=0)

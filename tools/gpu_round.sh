@@ -7,19 +7,21 @@ tag=${1:-round}
 O=gpurun_out/$tag
 rm -rf $O && mkdir -p $O
 export TMPDIR=/tmp
-B="--steps 20 --warmup 5"  # 32 priming + 5 warm-up launches precede the 20 timed ones: launches 38..57
+# 20 timed frames: a ring of 8, two frames per launch and one at each end of a stretch (FrameLoop::run), so 17 priming
+# and 4 warm-up launches precede the 11 timed ones: launches 21..31
+B="--steps 20 --warmup 5"
 timeout -k 10 200 python -u -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { echo "smoke failed"; tail -20 $O/smoke.log; exit 1; }
 tail -1 $O/smoke.log
 timeout -k 10 300 python -u bench.py $B > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -20 $O/bench.err; exit 1; }
 # the loop that leaves the frames in HBM, alone: under rocprofv3 the runtime turns the DMA copies of the metric's
 # loop into copy kernels that share the GPU with the render kernel, so that loop is traced separately below
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_hbm -- python3 bench.py $B --no-cpu-baseline --hbm-only > $O/trace_hbm_bench.json 2> $O/trace_hbm.err || { echo "rocprof (hbm) failed"; tail -20 $O/trace_hbm.err; exit 1; }
-python3 tools/timeline.py $O/trace_hbm 38 20 > $O/timeline_hbm.txt || exit 1
+python3 tools/timeline.py $O/trace_hbm 21 11 > $O/timeline_hbm.txt || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_host -- python3 bench.py $B --no-cpu-baseline --no-hbm-leg > $O/trace_host_bench.json 2> $O/trace_host.err || { echo "rocprof (host) failed"; tail -20 $O/trace_host.err; exit 1; }
-python3 tools/timeline.py $O/trace_host 38 20 > $O/timeline_host.txt || exit 1
+python3 tools/timeline.py $O/trace_host 21 11 > $O/timeline_host.txt || exit 1
 P="--steps 3 --warmup 1 --no-cpu-baseline --hbm-only"
-pass() {  # name, counters
-  timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $O/pmc/$1 -- python3 bench.py $P > $O/pmc_$1.out 2> $O/pmc_$1.err || { echo "pmc pass $1 failed"; tail -5 $O/pmc_$1.err; exit 1; }
+pass() {  # name, counters; one frame per launch, so that "per launch" is per frame
+  RT_AMD_FRAMES_PER_LAUNCH=1 timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $O/pmc/$1 -- python3 bench.py $P > $O/pmc_$1.out 2> $O/pmc_$1.err || { echo "pmc pass $1 failed"; tail -5 $O/pmc_$1.err; exit 1; }
 }
 mkdir -p $O/pmc
 pass fetch "FETCH_SIZE" && pass write "WRITE_SIZE" && \

@@ -3,7 +3,7 @@
 every part of N rendered alone on GPU 0 with its copies to the host, as each GPU of an N-GPU run does.  What an
 N-GPU node can reach at best is the slowest part's period; this needs one GPU only.  Per N and band height: the
 slowest part, and how unevenly the rays fall on the parts (max / min).
-usage: part_period.py [depth] [band rows ...]   (depth 0 or none: what bench.py takes, 4 frames for one part, else 16)"""
+usage: part_period.py [depth] [band rows ...]   (depth 0 or none: what bench.py takes for a long run, 16)"""
 import json
 import os
 import sys
@@ -23,7 +23,7 @@ for rows in HEIGHTS:
         if n == 1 and rows != HEIGHTS[0]:
             continue  # one part is the whole frame whatever the band height
         worst, rays = None, []
-        DEPTH = DEPTH_ARG or (4 if n == 1 else 16)
+        DEPTH = DEPTH_ARG or 16
         for part in range(n):
             loop = scene.frame_loop([0], depth=DEPTH, first_part=part, total_parts=n)  # the loop's own ring, as in bench.py
             assert loop.band_rows == rows
