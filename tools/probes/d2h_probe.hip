@@ -91,6 +91,24 @@ int main() {
       }
     }
   }
+  // several whole frames per copy: what the fixed cost of a copy is worth
+  {
+    hipStream_t copy;
+    CK(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    for (int per_copy : {1, 2, 4}) {
+      for (int rep = 0; rep < 2; rep++) {
+        CK(hipDeviceSynchronize());
+        auto t0 = std::chrono::steady_clock::now();
+        for (int f = 0; f < frames; f += per_copy) {
+          size_t slot = (f & 3) / per_copy * per_copy * bytes;
+          CK(hipMemcpyAsync(host + slot, dev + slot, bytes * per_copy, hipMemcpyDeviceToHost, copy));
+        }
+        CK(hipDeviceSynchronize());
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
+        if (rep) printf("%d whole frame(s) per copy: %.4f ms per frame, %.1f GB/s\n", per_copy, ms, bytes / ms * 1e-6);
+      }
+    }
+  }
   // the same for bands of 8 rows (what the frame loop deals), the copies of consecutive frames going round-robin
   // to one, two or three copy streams: does the fixed cost of one copy overlap the transfer of the next?
   {
