@@ -232,7 +232,7 @@ def bench_single_process(args, timed=None):
     dealt = None
     if n > 1 and not args.no_dealt_leg and not args.hbm_only:
         import threading
-        loops = [scene.frame_loop([d], depth=DEPTH) for d in devices]
+        loops = [scene.frame_loop([d], depth=depth) for d in devices]
         gate = threading.Barrier(n + 1)
 
         def deal(lp):
