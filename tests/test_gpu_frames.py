@@ -54,6 +54,48 @@ def test_frames_of_one_launch_equal_frames_rendered_alone(pkg, root, part, parts
             assert np.array_equal(frames[k].cpu().numpy(), want[k]), "frame %d of %d" % (k, count)
 
 
+@pytest.mark.parametrize("kind", ["large mesh", "csg"])
+def test_the_other_kernel_variants_render_several_frames_too(pkg, root, tmp_path, kind):
+    """A mesh large enough for the kernels that read wave-uniform nodes through the scalar cache and fetch a run's
+    next triangle ahead, and a scene with CSG operators (the general kernels): the same launches of several frames."""
+    import json
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import scenegen
+    if kind == "large mesh":
+        path, tris = scenegen.heightfield(str(tmp_path), cells=256, width=W, height=H, name="hf_frames")
+        scene = pkg.Scene.from_file(path, base_dir=root, device=0)
+        assert tris >= 100000
+        views = [([0.3 * k, 2.0 + 0.2 * k, -4.0 + 0.3 * k], [0.0, 0.0, 0.0]) for k in range(3)]
+    else:
+        base = json.load(open(os.path.join(root, "scenes", "example.json")))
+        z05 = scenegen.translation(0.0, 0.0, 0.5)
+        shapes = [{"ty": "difference", "children": [{"ty": "cube"}, {"ty": "sphere", "transform": z05}]},
+                  {"ty": "union", "transform": scenegen.translation(2.5, 0.0, 0.0), "children": [{"ty": "sphere"}, {"ty": "cylinder", "transform": z05}]},
+                  {"ty": "plane", "transform": scenegen.translation(0.0, -1.0, 0.0)}]
+        scene = pkg.Scene(json.dumps(dict(base, shapes=shapes)), root, device=0)
+        views = [([1.0 * k - 1.0, 1.5 + 0.5 * k, -6.0], [0.5, 0.0, 0.0]) for k in range(3)]
+    cams = []
+    for cam_from, cam_to in views:
+        scene.set_camera(W, H, 1.0472, cam_from, cam_to, [0.0, 1.0, 0.0])
+        cams.append(copy.deepcopy(scene.camera()))
+    for part, parts in ((0, 1), (1, 3)):
+        want = []
+        for k in range(3):
+            def put(k=k):
+                scene._camera = cams[k]
+            want.append(alone(scene, torch, put, part, parts, 8))
+        assert want[0].any() and not np.array_equal(want[0], want[1])
+        frames = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        scene.wait()
+        scene.render_frames_device(cams, [f.data_ptr() for f in frames], part=part, n_parts=parts, bands=parts > 1, band_rows=8)
+        st = scene.wait()
+        assert st.kernel_launches == 1 and st.generations == 3
+        for k in range(3):
+            assert np.array_equal(frames[k].cpu().numpy(), want[k]), "%s: frame %d, part %d of %d" % (kind, k, part, parts)
+
+
 def test_scenes_that_spawn_rays_get_their_frames_one_after_the_other(pkg, root):
     import torch
     scene = pkg.Scene.from_file(os.path.join(root, "scenes", "glass.json"), base_dir=root, device=0)
