@@ -261,6 +261,23 @@ def bench_single_process(args, timed=None):
             lp.close()
     roofline = roofline_of(counted, lone, piped, linfo["scene_bytes"], host_s / args.steps, n)
 
+    # Beside the metric: the same loop for a few seconds, in the ring of a long run.  The timed region above is a few
+    # milliseconds; this is what the loop sustains (and long enough for an outside observer of the GPU to see it busy).
+    sustained = None
+    if args.sustained_seconds > 0 and not (args.no_cpu_baseline or args.hbm_only):
+        long_depth = ring_depth(n, 1 << 20)
+        lp = loop if depth == long_depth else scene.frame_loop(devices, depth=long_depth)
+        lp.run(0, 64, True)
+        frames = max(1000, int(args.sustained_seconds / (host_s / args.steps)))
+        sec, st = lp.run(0, frames, True)
+        done = sum_stats(st)
+        sustained = {"value": (done["primary"] + done["shadow"] + done["reflect"] + done["refract"]) / sec, "unit": "rays/s",
+                     "frames": frames, "seconds": sec, "ms_per_step": sec / frames * 1e3,
+                     "pipeline": {"frames_in_flight_per_gpu": long_depth, "frames_of_a_part_per_launch_and_copy": lp.frames_per_launch},
+                     "note": "not the metric's timed region: the same frames to the host, back to back for a few seconds"}
+        if lp is not loop:
+            lp.close()
+
     cpu_baseline = None
     if n == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -328,6 +345,7 @@ def bench_single_process(args, timed=None):
         "frames_left_in_hbm": None if hbm_s is None else {
             "value": rays_per_frame * args.steps / hbm_s, "unit": "rays/s", "ms_per_step": hbm_s / args.steps * 1e3,
             "note": "the same loop without the copies to the host (not the metric's timed region)"},
+        "sustained": sustained,
         "whole_frames_dealt_to_the_gpus": None if dealt is None else {
             "value": n * rays_per_frame * args.steps / dealt, "unit": "rays/s", "frames_per_step": n,
             "ms_per_step": dealt / args.steps * 1e3, "scaling": "weak",
@@ -690,6 +708,8 @@ def main():
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "teapot.json"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the extra leg that leaves the frames in HBM")
+    ap.add_argument("--sustained-seconds", type=float, default=3.0,
+                    help="length of the extra leg that runs the loop back to back (0: none; none without the CPU baseline)")
     ap.add_argument("--hbm-only", action="store_true",
                     help="time only the loop that leaves the frames in HBM (for profiler runs: under rocprofv3 the runtime "
                          "turns the DMA copies to the host into copy kernels that share the GPU with the render kernel)")

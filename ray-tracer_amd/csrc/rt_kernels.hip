@@ -268,4 +268,19 @@ void launch_refit(hipStream_t stream, const RefitView& v) {
   hipLaunchKernelGGL(k_refit, dim3((v.n_nodes + 255) / 256), dim3(256), 0, stream, v);
 }
 
+// One wave that does nothing for `ticks` of the constant-rate counter (100 MHz): two of these on two streams take
+// once that time when the streams have hardware queues of their own and twice when they share one.
+__global__ void __launch_bounds__(64) k_linger(unsigned long long ticks, unsigned long long* sink) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long now = t0;
+  for (unsigned guard = 0; guard < (1u << 22) && now - t0 < ticks; guard++) {  // the guard ends it whatever the clock does
+    __builtin_amdgcn_s_sleep(8);
+    now = __builtin_amdgcn_s_memtime();
+  }
+  if (sink && threadIdx.x == 0) *sink = now - t0;  // a vector store
+}
+void launch_linger(hipStream_t stream, unsigned long long ticks, unsigned long long* sink) {
+  hipLaunchKernelGGL(k_linger, dim3(1), dim3(64), 0, stream, ticks, sink);
+}
+
 }  // namespace rt

@@ -33,5 +33,6 @@ void launch_points_shadowed(hipStream_t stream, const SceneDev& dev, bool genera
                             const double* pts, uint8_t* out);
 void launch_pixel_rays(hipStream_t stream, const CameraDev& cam, uint32_t n, const uint32_t* xy, double* rays6);
 void launch_refit(hipStream_t stream, const RefitView& v);
+void launch_linger(hipStream_t stream, unsigned long long ticks, unsigned long long* sink);
 
 }  // namespace rt

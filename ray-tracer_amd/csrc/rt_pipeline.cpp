@@ -414,7 +414,14 @@ static int verify_oldest(rt_scene* s, int upto);
 static int swap_lane(rt_scene* s, int spares) {
   rt_scene::Lane& o = s->spare_lane[s->next_spare % spares];
   s->next_spare = (s->next_spare + 1) % spares;
-  if (!o.stream) HIP_TRY(hipStreamCreateWithFlags(&o.stream, hipStreamNonBlocking));
+  if (!o.stream) {  // not on the queue of the copy stream, of the set in use or of another set that waits
+    std::vector<hipStream_t> avoid = {s->copy_stream, s->stream};
+    for (const rt_scene::Lane& other : s->spare_lane)
+      if (other.stream) avoid.push_back(other.stream);
+    for (hipStream_t st : avoid) HIP_TRY(hipStreamSynchronize(st));  // once per set: the measurement wants them idle
+    int rc = pick_streams(avoid.data(), (int)avoid.size(), 1, &o.stream);
+    if (rc) return rc;
+  }
   if (o.depth != s->depth) {
     int rc = release_lane(o);
     if (rc) return rc;

@@ -238,6 +238,9 @@ int collect_all(rt_scene* s);  // waits for the frames in flight (verifying thos
 // image buffers hold that device address; *was_frame tells whether one did.
 int verify_frames(rt_scene* s, const void* touching, bool* was_frame);
 int ensure_gen(rt_scene* s, int g, size_t cap);
+// `want` new streams of the current device, chosen so that they share a hardware queue neither with one another nor
+// with the `avoid` streams (which must be idle), as far as the process has queues for that (rt_scene_build.cpp).
+int pick_streams(const hipStream_t* avoid, int n_avoid, int want, hipStream_t* out);
 int ensure_depth(rt_scene* s, int depth);  // buffers, counters and events for a recursion that deep
 int ensure_aside(rt_scene* s, uint32_t rays);  // room for the shadow queries a generation of that many rays may set aside
 int stage_reserve(rt_scene* s, size_t bytes);
