@@ -206,3 +206,30 @@ def test_bench_with_one_loop_per_rank_says_that_the_frame_is_not_assembled(root)
     assert two["frame_sha256"] == one["frame_sha256"]
     assert two["config"]["frame_assembled_in_timed_region"] is False and "not assembled" in two["metric"]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("rt_amd_bench_")]
+
+
+def test_a_scene_chooses_streams_that_share_no_hardware_queue(pkg, root, capfd, monkeypatch):
+    """A scene takes its copy stream and its render streams from a pool, keeping those on which two lingering kernels
+    run side by side (streams on one hardware queue take turns, and a copy stream that shares one with a render
+    stream halves the frame loop's rate).  The choice is reported under RT_AMD_DEBUG; the frames are the same with
+    the streams as made (RT_AMD_NO_QUEUE_TEST)."""
+    import re
+    path = os.path.join(root, "scenes", "teapot.json")
+    monkeypatch.setenv("RT_AMD_DEBUG", "1")
+    chosen = pkg.Scene.from_file(path, base_dir=root, device=0)
+    err = capfd.readouterr().err
+    found = re.findall(r"streams: (\d+) of (\d+) on hardware queues of their own", err)
+    assert found, err
+    distinct, wanted = map(int, found[-1])
+    assert wanted == 4 and 2 <= distinct <= 4  # four hardware queues per process unless something else holds them
+    chosen.set_canvas(200, 150)
+    want = chosen.render(rgb64=False, hit_leaf=False)[0]["rgb8"]
+    monkeypatch.setenv("RT_AMD_NO_QUEUE_TEST", "1")
+    as_made = pkg.Scene.from_file(path, base_dir=root, device=None)
+    as_made.set_canvas(200, 150)
+    assert "streams:" not in capfd.readouterr().err
+    loop = as_made.frame_loop([0, 0], depth=8)
+    loop.run(1, 6, True)
+    for slot in range(6):
+        assert np.array_equal(loop.host_frame(slot), want)
+    loop.close()
