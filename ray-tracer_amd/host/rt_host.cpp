@@ -1267,9 +1267,8 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
   // are to be in flight (one renders, one is being copied, one waits for its slots), so a launch takes at most a
   // third of the ring, and a count that divides the ring keeps a launch's slots in one piece (one GPU rendering an
   // eighth of the teapot frame at 1080p, ms per frame on the host: 0.034 one at a time in a ring of 8, 0.024 two at
-  // a time, 0.019 four at a time in a ring of 12 or 16; four at a time in a ring of 8: 0.028).  More than four
-  // launches in flight are no help and for whole frames a loss (a ring of 8 one frame at a time: 0.29 ms per frame
-  // against 0.128 in a ring of 4; a ring of 12 two at a time: 0.23 against 0.120 in a ring of 8).
+  // a time, 0.019-0.021 four at a time in a ring of 12 or 16; four at a time in a ring of 8: 0.028).  More than four
+  // launches in flight are no help (whole frames one at a time: 0.128 ms per frame in a ring of 4 and in a ring of 8).
   size_t group = spawns_ ? 1 : 4;
   const bool asked = getenv("RT_AMD_FRAMES_PER_LAUNCH") != nullptr;
   if (asked) group = (size_t)std::max(1, atoi(getenv("RT_AMD_FRAMES_PER_LAUNCH")));
@@ -1283,11 +1282,10 @@ FrameLoop::Result FrameLoop::run(size_t warmup, size_t frames, bool to_host) {
     std::vector<int> fenced_by((size_t)depth_, -1);  // per slot: the slot whose fence covers this slot's last copy
     std::vector<int> unfenced;                        // slots copied since the last fence
     // At most three fenced copies (or pairs of copies) wait in the copy stream: the worker holds back a fourth until
-    // the oldest has gone through.  With more of them queued the same loop runs in one of two states, from one run
-    // to the next and within a run -- whole frames four per launch in a ring of 16: 0.119 or 0.127-0.131 ms per
-    // frame (0.156-0.160 in some processes), two per launch in a ring of 8: 0.121 or 0.125-0.129 (0.163) -- and with
-    // the limit only in the fast one (0.1190-0.1193 and 0.1210-0.1213, twelve runs each).  Two are too few for
-    // launches of four frames (0.127-0.129: the host's turn-around shows), one for any (0.142).
+    // the oldest has gone through.  With more of them queued the same loop alternates between two rates from one run
+    // to the next -- whole frames four per launch in a ring of 16: 0.116 or 0.118-0.125 ms per frame, two per launch
+    // in a ring of 12: 0.120 or 0.22-0.24 -- and with the limit every ring and launch size repeats to 0.0001 ms.  Two
+    // are too few for launches of four frames (0.127-0.129: the host's turn-around shows), one for any (0.142).
     std::vector<int> fences_out;  // slots whose fence was recorded and not yet waited for, oldest first
     auto fence_out = [&](int slot) {
       // a slot is fenced again only after its last fence was waited for (the ring): an older entry of it is done
