@@ -279,7 +279,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, int part, int n_parts, u
 
 /* Frames of a render loop, back to back.  With RT_FLAG_ASYNC, rt_render enqueues the frame on the
  * scene's stream and returns at once (stats is not written); at most eight such calls (rt_render or
- * rt_render_frames) are in flight, a ninth waits for the oldest.  A scene whose materials spawn reflection or refraction rays is a
+ * rt_render_frames) are in flight, a ninth waits for the oldest.  A scene whose materials spawn
+ * reflection or refraction rays is a
  * row of ray generations: its first frame for a camera size and depth is rendered one generation at a
  * time (the call blocks, its counts still go to rt_scene_wait); later frames launch every generation at
  * once on the queue lengths of the last frame and are only enqueued, up to three in flight.  Whether such
